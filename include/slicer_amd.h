@@ -1,0 +1,160 @@
+/*
+ * slicer_amd.h -- C ABI of the MI355X-native particle->grid mass-assignment path.
+ *
+ * This is the drop-in boundary behind SLICER's createDensityMaps()
+ * (reference: SLICER/densitymaps.h:161-165, body densitymaps.cpp:419-524, called
+ * from slicer-v2.cpp:204-206).  The reference has no FFI; its seam is a C++ free
+ * function over std::valarray / std::vector / ifstream.  The adapter in
+ * slicer_amd/csrc/densitymaps_amd.{hpp,cpp} keeps that C++ signature and forwards
+ * to the entry points below, which are what a binding for this path would bind:
+ * plain pointers, sizes and PODs only -- no C++ types, no torch types.
+ *
+ * Call sequence for one lens plane (= one createDensityMaps call), per device:
+ *
+ *   slicer_create()                                  once per device
+ *   slicer_plane_begin(desc)                         densitymaps.cpp:426-431  (resize/zero maps)
+ *   for each snapshot sub-file ff in [ffmin,ffmax):  densitymaps.cpp:432
+ *     slicer_file_begin(file)                        Header + Random entry    (:438, gadget2io.cpp:204-270)
+ *     for each particle type t with npart[t] > 0:
+ *       slicer_deposit_host|device(t, pos, mass, n)  readPos + mapParticles + gridist_w
+ *     slicer_file_end()                              densitymaps.cpp:511-513  (per-file accumulation)
+ *   slicer_plane_finalize()                          device maps final (ready for the cross-rank sum,
+ *                                                    slicer-v2.cpp:214-217 -> RCCL, see slicer_amd_rccl.h)
+ *   slicer_plane_read(...)                           D2H into the caller's valarrays; reports the
+ *                                                    negativity guard of densitymaps.cpp:334-345
+ *
+ * All functions return 0 on success and a SLICER_ERR_* code otherwise; they never
+ * exit(), abort() or throw across the boundary (the reference returns 1 and lets
+ * main() MPI_Abort: slicer-v2.cpp:204-207; gridist_w calls exit(-1): utilities.cpp:55-64).
+ * A handle is not thread-safe; different handles are independent (one per GPU).
+ */
+#ifndef SLICER_AMD_H
+#define SLICER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLICER_AMD_VERSION 100 /* 0.1.0 */
+#define SLICER_MAX_PLANES 8
+
+/* status codes */
+#define SLICER_OK 0
+#define SLICER_ERR_NEGATIVE_COORD 1 /* densitymaps.cpp:334-345 "I will STOP here" -> reference returns 1 */
+#define SLICER_ERR_ARG 2
+#define SLICER_ERR_STATE 3
+#define SLICER_ERR_HIP 4
+#define SLICER_ERR_NOMEM 5
+#define SLICER_ERR_UNSUPPORTED 6 /* snopt > 0 (order-dependent libc rand() thinning, densitymaps.cpp:387-397) */
+#define SLICER_ERR_NO_DEVICE 7
+
+/* mass-assignment scheme: DO_NGP is a compile-time macro in the reference (densitymaps.h:22),
+ * a run-time argument of gridist_w (utilities.h:140) and a run-time field here. */
+#define SLICER_MAS_TSC 0
+#define SLICER_MAS_NGP 1
+
+/* accumulator of the TSC maps (NGP always uses exact u32 counts when the mass is constant) */
+#define SLICER_ACC_F32 0     /* f32 atomics: fastest, order-dependent in the last bits            */
+#define SLICER_ACC_F64 1     /* f64 atomics, rounded to f32 once at finalize                       */
+#define SLICER_ACC_FIXED64 2 /* 64-bit fixed point: order-independent => bitwise reproducible sums */
+
+/* deposit algorithm */
+#define SLICER_ALGO_AUTO 0
+#define SLICER_ALGO_DIRECT 1 /* fused project + global atomics                                   */
+#define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush */
+
+typedef struct slicer_handle_s *slicer_handle;
+
+/* One pass = up to SLICER_MAX_PLANES lens planes cut from the same box replication (same Random
+ * entry and rcase: densitymaps.cpp:227-246, slicer-v2.cpp:184-185).  n_planes = 1 reproduces one
+ * createDensityMaps call.  ld/ld2 are Lens.ld/ld2 in Mpc/h (data.h:111-112). */
+typedef struct {
+    int32_t npix;                          /* InputParams.npix (data.h:31)                       */
+    int32_t n_planes;                      /* 1..SLICER_MAX_PLANES                               */
+    int32_t mas;                           /* SLICER_MAS_*                                       */
+    int32_t accum;                         /* SLICER_ACC_*  (TSC)                                */
+    int32_t algo;                          /* SLICER_ALGO_*                                      */
+    int32_t hydro;                         /* InputParams.hydro (data.h:35)                      */
+    int32_t snopt;                         /* InputParams.snopt (data.h:45); must be 0           */
+    int32_t want_type_maps;                /* 1: keep the six per-type maps (mapxytoti)          */
+    double fov_rad;                        /* fovradiants                                        */
+    double ld[SLICER_MAX_PLANES];          /* Lens.ld[isnap]                                     */
+    double ld2[SLICER_MAX_PLANES];         /* Lens.ld2[isnap]                                    */
+    int32_t nrepperp[SLICER_MAX_PLANES];   /* Lens.nrepperp[isnap] (data.h:114)                  */
+    int32_t fixed_frac_bits;               /* SLICER_ACC_FIXED64: fractional bits, 0 = auto (40) */
+    int32_t reserved;
+} slicer_plane_desc;
+
+/* Per sub-file state: the fields of Header (data.h:59-79) and of the plane's Random entry
+ * (data.h:126-131) that the path reads, plus rcase (slicer-v2.cpp:184-185). */
+typedef struct {
+    int32_t npart[6];   /* Header.npart                                  */
+    double massarr[6];  /* Header.massarr                                */
+    double boxsize;     /* Header.boxsize (kpc/h; POS_U = 1)             */
+    int32_t sgn[3];     /* Random.sgnX/Y/Z[isnap]  (+1 / -1)             */
+    int32_t face;       /* Random.face[isnap]      (1..6)                */
+    double center[3];   /* Random.x0/y0/z0[isnap]                        */
+    float rcase;        /* box-replication offset along the line of sight */
+    int32_t reserved;
+} slicer_file_desc;
+
+typedef struct {
+    char name[32];
+    uint64_t launches;
+    double total_ms; /* summed HIP-event time of those launches */
+} slicer_kernel_time;
+
+int slicer_version(void);
+
+/* device = HIP device ordinal.  max_chunk = largest number of particles one deposit call may
+ * carry in one kernel pass (bigger inputs are looped internally); sizes the workspace. */
+int slicer_create(int device, uint64_t max_chunk, slicer_handle *out);
+int slicer_destroy(slicer_handle h);
+const char *slicer_last_error(slicer_handle h); /* valid until the next call on h; h may be NULL */
+
+/* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = handle-owned. */
+int slicer_set_stream(slicer_handle h, void *hip_stream);
+
+int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc);
+int slicer_file_begin(slicer_handle h, const slicer_file_desc *file);
+/* pos: AoS [n][3] f32 exactly as in the POS block (raw file units), host memory.  mass: per-particle
+ * f32 masses (hydro types with massarr == 0: MASS / BHMA stream, densitymaps.cpp:358-372) or NULL. */
+int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float *mass, uint64_t n);
+/* same, operands already resident in this device's HBM */
+int slicer_deposit_device(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n);
+int slicer_file_end(slicer_handle h);
+int slicer_plane_finalize(slicer_handle h);
+
+/* Device pointers of the finalized f32 maps of plane `plane` (npix*npix each): *d_tot, and
+ * d_toti[0..5] (NULL for types that never appeared or when want_type_maps == 0). */
+int slicer_plane_device_maps(slicer_handle h, int plane, float **d_tot, float **d_toti);
+/* Synchronise, run the guard check, copy maps to host.  tot: npix^2 floats; toti: 6*npix^2 floats or
+ * NULL; nsel: 6 int64 (true number of selected particles per type; the reference's own out-parameter
+ * is always 0 because of the shadowed array at densitymaps.cpp:497) or NULL. */
+int slicer_plane_read(slicer_handle h, int plane, float *tot, float *toti, int64_t *nsel);
+int slicer_synchronize(slicer_handle h);
+
+/* --- utilities for benches and tests (device-side synthetic boxes) --- */
+int slicer_device_malloc(slicer_handle h, size_t bytes, void **d_ptr);
+int slicer_device_free(slicer_handle h, void *d_ptr);
+int slicer_copy_to_device(slicer_handle h, void *d_dst, const void *src, size_t bytes);
+int slicer_copy_to_host(slicer_handle h, void *dst, const void *d_src, size_t bytes);
+int slicer_synth_positions(slicer_handle h, float *d_pos, uint64_t first, uint64_t count, double boxsize,
+                           uint64_t seed, int clustered);
+/* project only: writes xs, ys (and the plane index) of every selected entry of one chunk, in no
+ * particular order, plus the source particle index; returns the count.  For parity tests of A1-A3. */
+int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t n, float *d_xs, float *d_ys,
+                         int32_t *d_plane, uint64_t *d_src, uint64_t capacity, uint64_t *n_out);
+
+/* per-kernel HIP-event timing (off by default; adds two event records per launch) */
+int slicer_profile_enable(slicer_handle h, int on);
+int slicer_profile_reset(slicer_handle h);
+int slicer_profile_get(slicer_handle h, slicer_kernel_time *out, int capacity, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLICER_AMD_H */

@@ -1,0 +1,873 @@
+// slicer_capi.cpp -- implementation of the C ABI declared in include/slicer_amd.h.
+// Host-side orchestration only: buffers, streams, staging, launch selection, error mapping.
+// Reference behaviour mirrored per entry point is cited in the header.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/slicer_amd.h"
+#include "slicer_kernels.hpp"
+
+using namespace slicer;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct PlaneBufs {
+    DevBuf tot;
+    DevBuf toti[6];
+    DevBuf acc[6];  // F64/FIXED accumulators, or NGP per-file scratch
+    DevBuf acc_shared;
+};
+
+struct ProfEntry {
+    int name;
+    hipEvent_t e0, e1;
+};
+
+const char *kKernelNames[] = {"direct_deposit", "finalize_tsc", "fold_ngp",  "synth",
+                              "project_bin",    "bin_scan",     "bin_scatter", "tile_deposit", "debug_project"};
+enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SCATTER, KN_TILE, KN_DEBUG, KN_COUNT };
+
+}  // namespace
+
+struct slicer_handle_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipStream_t own = nullptr;
+    uint64_t max_chunk = 0;
+    std::string err;
+
+    bool in_plane = false, in_file = false, finalized = false;
+    slicer_plane_desc desc{};
+    slicer_file_desc file{};
+    uint64_t npix2 = 0;
+    PlaneBufs planes[SLICER_MAX_PLANES];
+    unsigned long long *d_counts = nullptr;  // [SLICER_MAX_PLANES][6]
+    int *d_neg = nullptr;
+    bool type_seen[6] = {};       // in this plane pass
+    bool shared_seen = false;
+    int file_mode[6] = {};        // NGP fold mode of the current file
+    float file_mconst[6] = {};
+    int fixed_exp[6] = {};
+    int fixed_exp_shared = 0;
+    bool fixed_exp_set[6] = {};
+    bool fixed_shared_set = false;
+
+    // host->device staging (double buffered)
+    float *h_stage[2] = {nullptr, nullptr};
+    float *d_stage[2] = {nullptr, nullptr};
+    float *h_mstage[2] = {nullptr, nullptr};
+    float *d_mstage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+    uint64_t stage_cap = 0;  // particles
+
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[KN_COUNT] = {};
+    uint64_t prof_n[KN_COUNT] = {};
+};
+
+namespace {
+
+thread_local std::string g_null_err;
+
+int fail(slicer_handle h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h)
+        h->err = buf;
+    else
+        g_null_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(h, e_ == hipErrorOutOfMemory ? SLICER_ERR_NOMEM : SLICER_ERR_HIP,            \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(slicer_handle h, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes)
+        return SLICER_OK;
+    if (b.p)
+        HIPCHK(h, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIPCHK(h, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SLICER_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+hipEvent_t get_event(slicer_handle h)
+{
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    slicer_handle h;
+    int name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(slicer_handle h_, int name_) : h(h_), name(name_)
+    {
+        if (h->profiling) {
+            e0 = get_event(h);
+            e1 = get_event(h);
+            (void)hipEventRecord(e0, h->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (h->profiling) {
+            (void)hipEventRecord(e1, h->stream);
+            h->prof.push_back({name, e0, e1});
+        }
+    }
+};
+
+void prof_collect(slicer_handle h)
+{
+    for (auto &p : h->prof) {
+        (void)hipEventSynchronize(p.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            h->prof_ms[p.name] += ms;
+            h->prof_n[p.name] += 1;
+        }
+        h->ev_pool.push_back(p.e0);
+        h->ev_pool.push_back(p.e1);
+    }
+    h->prof.clear();
+}
+
+float ceil_to_f32(double v)
+{
+    // smallest float >= v
+    float f = (float)v;
+    if ((double)f < v)
+        f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+int acc_kind(const slicer_plane_desc &d, bool has_mass)
+{
+    if (d.mas == SLICER_MAS_NGP)
+        return has_mass ? kF32 : kCountU32;
+    switch (d.accum) {
+    case SLICER_ACC_F64: return kF64;
+    case SLICER_ACC_FIXED64: return kFixed64;
+    default: return kF32;
+    }
+}
+
+size_t acc_elem_size(int kind) { return (kind == kF64 || kind == kFixed64) ? 8 : 4; }
+
+// Build the uniform parameter block for (current file, type).
+void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
+{
+    const slicer_plane_desc &d = h->desc;
+    const slicer_file_desc &f = h->file;
+    memset(&P, 0, sizeof P);
+    P.box = f.boxsize;
+    P.inv_box = 1.0 / f.boxsize;
+    for (int a = 0; a < 3; a++) {
+        P.c0[a] = f.center[a];
+        P.sgn[a] = (float)f.sgn[a];
+    }
+    // gadget2io.cpp:222-252: face -> (x,y,z) = wrapped[perm]
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
+    int fi = (f.face >= 1 && f.face <= 6) ? f.face - 1 : 0;  // any other value leaves case 1 (switch falls through)
+    for (int a = 0; a < 3; a++)
+        P.perm[a] = perms[fi][a];
+    P.rcase = f.rcase;
+    P.n_planes = d.n_planes;
+    for (int p = 0; p < d.n_planes; p++) {
+        double minDist = d.ld[p] / f.boxsize * 1.e+3 / 1.0;   // densitymaps.cpp:346 (POS_U = 1.0)
+        double maxDist = d.ld2[p] / f.boxsize * 1.e+3 / 1.0;  // densitymaps.cpp:347
+        P.zlo[p] = ceil_to_f32(minDist);
+        P.zhi[p] = ceil_to_f32(maxDist);
+        P.nrep[p] = d.nrepperp[p];
+    }
+    P.fov = d.fov_rad;
+    P.lim = d.fov_rad * (1. + 2. / d.npix) * 0.5;  // densitymaps.cpp:383
+    P.nn = d.npix;
+    P.pow2 = is_pow2(d.npix) ? 1 : 0;
+    P.dl = 1. / double(d.npix);  // utilities.cpp:50
+    P.nn_d = (double)d.npix;
+    P.half_dl = 0.5 * P.dl;
+    P.onehalf_dl = 0.5 * 3.0 * P.dl;
+    P.mconst = (float)f.massarr[type];  // densitymaps.cpp:372
+    P.sm_const = sqrtf(P.mconst);       // glibc sqrtf is correctly rounded, as std::sqrt(float)
+    int e = d.want_type_maps ? h->fixed_exp[type] : h->fixed_exp_shared;
+    P.fixed_scale = std::ldexp(1.0, e);
+    (void)has_mass;
+}
+
+int pick_fixed_exp(const slicer_plane_desc &d, double m, bool has_mass)
+{
+    int frac = d.fixed_frac_bits > 0 ? d.fixed_frac_bits : 40;
+    int le = 10;  // MAX_M = 1e3 < 2^10
+    if (!has_mass && m > 0 && std::isfinite(m))
+        le = std::ilogb(m) + 1;
+    return frac - le;
+}
+
+int zero_async(slicer_handle h, void *p, size_t bytes)
+{
+    HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    return SLICER_OK;
+}
+
+// Make sure the destination buffers of `type` exist and are zeroed for this plane pass.
+int prepare_type(slicer_handle h, int type, bool has_mass)
+{
+    const slicer_plane_desc &d = h->desc;
+    const size_t n4 = h->npix2 * 4;
+    const int kind = acc_kind(d, has_mass);
+    const bool ngp = d.mas == SLICER_MAS_NGP;
+    const bool shared = !ngp && !d.want_type_maps;
+    if (shared) {
+        if (!h->shared_seen) {
+            if (!h->fixed_shared_set) {
+                double mm = 0;
+                bool any_mass = false;
+                for (int t = 0; t < 6; t++)
+                    if (h->file.npart[t] > 0) {
+                        if (d.hydro && h->file.massarr[t] == 0)
+                            any_mass = true;
+                        mm = std::max(mm, h->file.massarr[t]);
+                    }
+                h->fixed_exp_shared = pick_fixed_exp(d, mm, any_mass);
+                h->fixed_shared_set = true;
+            }
+            for (int p = 0; p < d.n_planes; p++) {
+                int rc = ensure(h, h->planes[p].acc_shared, h->npix2 * acc_elem_size(kind));
+                if (rc)
+                    return rc;
+                rc = zero_async(h, h->planes[p].acc_shared.p, h->npix2 * acc_elem_size(kind));
+                if (rc)
+                    return rc;
+            }
+            h->shared_seen = true;
+        }
+        return SLICER_OK;
+    }
+    if (!h->type_seen[type]) {
+        if (!h->fixed_exp_set[type]) {
+            h->fixed_exp[type] = pick_fixed_exp(d, h->file.massarr[type], has_mass);
+            h->fixed_exp_set[type] = true;
+        }
+        for (int p = 0; p < d.n_planes; p++) {
+            int rc = ensure(h, h->planes[p].toti[type], n4);
+            if (rc)
+                return rc;
+            rc = zero_async(h, h->planes[p].toti[type].p, n4);
+            if (rc)
+                return rc;
+            if (ngp || kind != kF32) {
+                size_t b = h->npix2 * (ngp ? 4 : acc_elem_size(kind));
+                rc = ensure(h, h->planes[p].acc[type], b);
+                if (rc)
+                    return rc;
+                rc = zero_async(h, h->planes[p].acc[type].p, b);
+                if (rc)
+                    return rc;
+            }
+        }
+        h->type_seen[type] = true;
+    }
+    return SLICER_OK;
+}
+
+void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
+{
+    const slicer_plane_desc &d = h->desc;
+    const int kind = acc_kind(d, has_mass);
+    const bool ngp = d.mas == SLICER_MAS_NGP;
+    const bool shared = !ngp && !d.want_type_maps;
+    memset(&T, 0, sizeof T);
+    for (int p = 0; p < d.n_planes; p++) {
+        if (shared)
+            T.acc[p] = h->planes[p].acc_shared.p;
+        else if (ngp || kind != kF32)
+            T.acc[p] = h->planes[p].acc[type].p;
+        else
+            T.acc[p] = h->planes[p].toti[type].p;
+        T.nsel[p] = h->d_counts + (size_t)p * 6 + type;
+    }
+    T.neg_flag = h->d_neg;
+}
+
+int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n)
+{
+    const slicer_plane_desc &d = h->desc;
+    const bool has_mass = d_mass != nullptr;
+    PassParams P;
+    make_params(h, type, has_mass, P);
+    Targets T;
+    fill_targets(h, type, has_mass, T);
+    LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
+    {
+        ProfScope ps(h, KN_DIRECT);
+        HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
+    }
+    return SLICER_OK;
+}
+
+int check_deposit_args(slicer_handle h, int type, const void *pos, const void *mass, uint64_t n)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane || !h->in_file)
+        return fail(h, SLICER_ERR_STATE, "deposit outside slicer_plane_begin/slicer_file_begin");
+    if (type < 0 || type > 5)
+        return fail(h, SLICER_ERR_ARG, "particle type %d out of range 0..5", type);
+    if (n && !pos)
+        return fail(h, SLICER_ERR_ARG, "null position pointer with n = %llu", (unsigned long long)n);
+    (void)mass;
+    return SLICER_OK;
+}
+
+int begin_type(slicer_handle h, int type, bool has_mass)
+{
+    const slicer_plane_desc &d = h->desc;
+    int rc = prepare_type(h, type, has_mass);
+    if (rc)
+        return rc;
+    if (d.mas == SLICER_MAS_NGP) {
+        int mode = has_mass ? 2 : 1;
+        if (h->file_mode[type] && h->file_mode[type] != mode)
+            return fail(h, SLICER_ERR_ARG, "type %d deposited both with and without per-particle masses in one file",
+                        type);
+        h->file_mode[type] = mode;
+        h->file_mconst[type] = (float)h->file.massarr[type];
+    }
+    return SLICER_OK;
+}
+
+int ensure_staging(slicer_handle h, bool need_mass)
+{
+    uint64_t cap = h->max_chunk;
+    if (h->stage_cap < cap) {
+        for (int i = 0; i < 2; i++) {
+            if (h->h_stage[i])
+                (void)hipHostFree(h->h_stage[i]);
+            if (h->d_stage[i])
+                (void)hipFree(h->d_stage[i]);
+            h->h_stage[i] = h->d_stage[i] = nullptr;
+            if (h->h_mstage[i])
+                (void)hipHostFree(h->h_mstage[i]);
+            if (h->d_mstage[i])
+                (void)hipFree(h->d_mstage[i]);
+            h->h_mstage[i] = h->d_mstage[i] = nullptr;
+            HIPCHK(h, hipHostMalloc((void **)&h->h_stage[i], cap * 12, hipHostMallocDefault));
+            HIPCHK(h, hipMalloc((void **)&h->d_stage[i], cap * 12));
+            if (!h->stage_free[i])
+                HIPCHK(h, hipEventCreateWithFlags(&h->stage_free[i], hipEventDisableTiming));
+        }
+        h->stage_cap = cap;
+    }
+    if (need_mass && !h->h_mstage[0]) {
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(h, hipHostMalloc((void **)&h->h_mstage[i], h->stage_cap * 4, hipHostMallocDefault));
+            HIPCHK(h, hipMalloc((void **)&h->d_mstage[i], h->stage_cap * 4));
+        }
+    }
+    return SLICER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slicer_version(void) { return SLICER_AMD_VERSION; }
+
+const char *slicer_last_error(slicer_handle h) { return h ? h->err.c_str() : g_null_err.c_str(); }
+
+int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
+{
+    if (!out)
+        return fail(nullptr, SLICER_ERR_ARG, "slicer_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SLICER_ERR_NO_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, SLICER_ERR_ARG, "device %d out of range (have %d)", device, ndev);
+    slicer_handle h = new (std::nothrow) slicer_handle_s;
+    if (!h)
+        return fail(nullptr, SLICER_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->max_chunk = max_chunk ? max_chunk : (1ull << 24);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->own) != hipSuccess ||
+        hipMalloc((void **)&h->d_counts, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6) != hipSuccess ||
+        hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess) {
+        int rc = fail(nullptr, SLICER_ERR_HIP, "device %d initialisation failed: %s", device,
+                      hipGetErrorString(hipGetLastError()));
+        delete h;
+        return rc;
+    }
+    h->stream = h->own;
+    *out = h;
+    return SLICER_OK;
+}
+
+int slicer_destroy(slicer_handle h)
+{
+    if (!h)
+        return SLICER_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    prof_collect(h);
+    for (auto e : h->ev_pool)
+        (void)hipEventDestroy(e);
+    for (auto &pl : h->planes) {
+        release(pl.tot);
+        release(pl.acc_shared);
+        for (int t = 0; t < 6; t++) {
+            release(pl.toti[t]);
+            release(pl.acc[t]);
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        if (h->d_stage[i]) (void)hipFree(h->d_stage[i]);
+        if (h->h_mstage[i]) (void)hipHostFree(h->h_mstage[i]);
+        if (h->d_mstage[i]) (void)hipFree(h->d_mstage[i]);
+        if (h->stage_free[i]) (void)hipEventDestroy(h->stage_free[i]);
+    }
+    if (h->d_counts) (void)hipFree(h->d_counts);
+    if (h->d_neg) (void)hipFree(h->d_neg);
+    if (h->own) (void)hipStreamDestroy(h->own);
+    delete h;
+    return SLICER_OK;
+}
+
+int slicer_set_stream(slicer_handle h, void *hip_stream)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (h->in_plane)
+        return fail(h, SLICER_ERR_STATE, "cannot change stream inside a plane pass");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own;
+    return SLICER_OK;
+}
+
+int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
+{
+    if (!h || !desc)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (desc->npix <= 0 || desc->npix > 65536)
+        return fail(h, SLICER_ERR_ARG, "npix %d out of range", desc->npix);
+    if (desc->n_planes < 1 || desc->n_planes > SLICER_MAX_PLANES)
+        return fail(h, SLICER_ERR_ARG, "n_planes %d out of range 1..%d", desc->n_planes, SLICER_MAX_PLANES);
+    if (desc->mas != SLICER_MAS_TSC && desc->mas != SLICER_MAS_NGP)
+        return fail(h, SLICER_ERR_ARG, "unknown mass-assignment scheme %d", desc->mas);
+    if (desc->accum < SLICER_ACC_F32 || desc->accum > SLICER_ACC_FIXED64)
+        return fail(h, SLICER_ERR_ARG, "unknown accumulator %d", desc->accum);
+    if (desc->snopt != 0)
+        return fail(h, SLICER_ERR_UNSUPPORTED,
+                    "snopt = %d: shot-noise thinning draws from the process-global libc rand() stream in selection "
+                    "order (densitymaps.cpp:387-397); not supported on the device path",
+                    desc->snopt);
+    if (!(desc->fov_rad > 0))
+        return fail(h, SLICER_ERR_ARG, "fov_rad must be > 0");
+    for (int p = 0; p < desc->n_planes; p++)
+        if (desc->nrepperp[p] < 0 || desc->nrepperp[p] > 8)
+            return fail(h, SLICER_ERR_ARG, "nrepperp[%d] = %d out of range 0..8", p, desc->nrepperp[p]);
+    HIPCHK(h, hipSetDevice(h->device));
+    h->desc = *desc;
+    h->npix2 = (uint64_t)desc->npix * (uint64_t)desc->npix;
+    h->in_plane = true;
+    h->in_file = false;
+    h->finalized = false;
+    h->shared_seen = false;
+    h->fixed_shared_set = false;
+    for (int t = 0; t < 6; t++) {
+        h->type_seen[t] = false;
+        h->fixed_exp_set[t] = false;
+        h->file_mode[t] = 0;
+    }
+    for (int p = 0; p < desc->n_planes; p++) {
+        int rc = ensure(h, h->planes[p].tot, h->npix2 * 4);
+        if (rc)
+            return rc;
+        if (desc->mas == SLICER_MAS_NGP) {  // the NGP fold accumulates into tot; TSC finalize overwrites it
+            rc = zero_async(h, h->planes[p].tot.p, h->npix2 * 4);
+            if (rc)
+                return rc;
+        }
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_neg, 0, sizeof(int), h->stream));
+    return SLICER_OK;
+}
+
+int slicer_file_begin(slicer_handle h, const slicer_file_desc *file)
+{
+    if (!h || !file)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (!h->in_plane || h->finalized)
+        return fail(h, SLICER_ERR_STATE, "slicer_file_begin outside a plane pass");
+    if (h->in_file)
+        return fail(h, SLICER_ERR_STATE, "slicer_file_begin: previous file not ended");
+    if (!(file->boxsize > 0))
+        return fail(h, SLICER_ERR_ARG, "boxsize must be > 0");
+    for (int a = 0; a < 3; a++)
+        if (file->sgn[a] != 1 && file->sgn[a] != -1)
+            return fail(h, SLICER_ERR_ARG, "sgn[%d] = %d is not +-1", a, file->sgn[a]);
+    h->file = *file;
+    h->in_file = true;
+    for (int t = 0; t < 6; t++)
+        h->file_mode[t] = 0;
+    return SLICER_OK;
+}
+
+int slicer_deposit_device(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n)
+{
+    int rc = check_deposit_args(h, type, d_pos, d_mass, n);
+    if (rc)
+        return rc;
+    if (n == 0)
+        return SLICER_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = begin_type(h, type, d_mass != nullptr);
+    if (rc)
+        return rc;
+    // one kernel pass per max_chunk particles keeps the workspace bounded
+    for (uint64_t off = 0; off < n; off += h->max_chunk) {
+        uint64_t c = std::min<uint64_t>(h->max_chunk, n - off);
+        rc = deposit_device_chunk(h, type, d_pos + 3 * off, d_mass ? d_mass + off : nullptr, c);
+        if (rc)
+            return rc;
+    }
+    return SLICER_OK;
+}
+
+int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float *mass, uint64_t n)
+{
+    int rc = check_deposit_args(h, type, pos, mass, n);
+    if (rc)
+        return rc;
+    if (n == 0)
+        return SLICER_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = begin_type(h, type, mass != nullptr);
+    if (rc)
+        return rc;
+    rc = ensure_staging(h, mass != nullptr);
+    if (rc)
+        return rc;
+    int slot = 0;
+    for (uint64_t off = 0; off < n; off += h->stage_cap, slot ^= 1) {
+        uint64_t c = std::min<uint64_t>(h->stage_cap, n - off);
+        // the slot is reusable once the kernel that read it has finished
+        HIPCHK(h, hipEventSynchronize(h->stage_free[slot]));
+        memcpy(h->h_stage[slot], pos + 3 * off, c * 12);
+        HIPCHK(h, hipMemcpyAsync(h->d_stage[slot], h->h_stage[slot], c * 12, hipMemcpyHostToDevice, h->stream));
+        const float *dm = nullptr;
+        if (mass) {
+            memcpy(h->h_mstage[slot], mass + off, c * 4);
+            HIPCHK(h, hipMemcpyAsync(h->d_mstage[slot], h->h_mstage[slot], c * 4, hipMemcpyHostToDevice, h->stream));
+            dm = h->d_mstage[slot];
+        }
+        rc = deposit_device_chunk(h, type, h->d_stage[slot], dm, c);
+        if (rc)
+            return rc;
+        HIPCHK(h, hipEventRecord(h->stage_free[slot], h->stream));
+    }
+    return SLICER_OK;
+}
+
+int slicer_file_end(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_file)
+        return fail(h, SLICER_ERR_STATE, "slicer_file_end without slicer_file_begin");
+    h->in_file = false;
+    if (h->desc.mas == SLICER_MAS_NGP) {
+        bool any = false;
+        for (int t = 0; t < 6; t++)
+            any |= h->file_mode[t] != 0;
+        if (any) {
+            for (int p = 0; p < h->desc.n_planes; p++) {
+                FoldArgs A;
+                memset(&A, 0, sizeof A);
+                for (int t = 0; t < 6; t++) {
+                    A.mode[t] = h->file_mode[t];
+                    A.mconst[t] = h->file_mconst[t];
+                    A.scratch[t] = h->file_mode[t] ? h->planes[p].acc[t].p : nullptr;
+                    A.toti[t] = h->file_mode[t] ? (float *)h->planes[p].toti[t].p : nullptr;
+                }
+                A.tot = (float *)h->planes[p].tot.p;
+                A.npix2 = h->npix2;
+                ProfScope ps(h, KN_FOLD);
+                HIPCHK(h, launch_fold_ngp(A, h->stream));
+            }
+        }
+    }
+    return SLICER_OK;
+}
+
+int slicer_plane_finalize(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_finalize outside a plane pass");
+    if (h->in_file)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_finalize: file not ended");
+    if (h->finalized)
+        return SLICER_OK;
+    const slicer_plane_desc &d = h->desc;
+    if (d.mas == SLICER_MAS_TSC) {
+        const int kind = acc_kind(d, false);
+        for (int p = 0; p < d.n_planes; p++) {
+            FinalizeArgs A;
+            memset(&A, 0, sizeof A);
+            bool any = false;
+            if (!d.want_type_maps) {
+                A.acc_shared = h->shared_seen ? h->planes[p].acc_shared.p : nullptr;
+                A.inv_scale_shared = std::ldexp(1.0, -h->fixed_exp_shared);
+                any = h->shared_seen;
+            } else {
+                for (int t = 0; t < 6; t++) {
+                    if (!h->type_seen[t])
+                        continue;
+                    any = true;
+                    A.acc[t] = kind == kF32 ? h->planes[p].toti[t].p : h->planes[p].acc[t].p;
+                    A.toti[t] = (float *)h->planes[p].toti[t].p;
+                    A.inv_scale[t] = std::ldexp(1.0, -h->fixed_exp[t]);
+                }
+            }
+            A.tot = (float *)h->planes[p].tot.p;
+            A.npix2 = h->npix2;
+            if (!any) {
+                int rc = zero_async(h, A.tot, h->npix2 * 4);
+                if (rc)
+                    return rc;
+                continue;
+            }
+            ProfScope ps(h, KN_FINALIZE);
+            HIPCHK(h, launch_finalize_tsc(kind, A, h->stream));
+        }
+    }
+    h->finalized = true;
+    return SLICER_OK;
+}
+
+int slicer_plane_device_maps(slicer_handle h, int plane, float **d_tot, float **d_toti)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane || !h->finalized)
+        return fail(h, SLICER_ERR_STATE, "maps are available after slicer_plane_finalize");
+    if (plane < 0 || plane >= h->desc.n_planes)
+        return fail(h, SLICER_ERR_ARG, "plane %d out of range", plane);
+    if (d_tot)
+        *d_tot = (float *)h->planes[plane].tot.p;
+    if (d_toti)
+        for (int t = 0; t < 6; t++)
+            d_toti[t] = h->type_seen[t] ? (float *)h->planes[plane].toti[t].p : nullptr;
+    return SLICER_OK;
+}
+
+int slicer_synchronize(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLICER_OK;
+}
+
+int slicer_plane_read(slicer_handle h, int plane, float *tot, float *toti, int64_t *nsel)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_read outside a plane pass");
+    if (plane < 0 || plane >= h->desc.n_planes)
+        return fail(h, SLICER_ERR_ARG, "plane %d out of range", plane);
+    int rc = slicer_plane_finalize(h);
+    if (rc)
+        return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int neg = 0;
+    HIPCHK(h, hipMemcpy(&neg, h->d_neg, sizeof neg, hipMemcpyDeviceToHost));
+    if (neg)
+        return fail(h, SLICER_ERR_NEGATIVE_COORD,
+                    "a transformed coordinate is negative (positions outside [0, 2*boxsize]?): the reference stops "
+                    "here (densitymaps.cpp:334-345)");
+    const size_t n4 = h->npix2 * 4;
+    if (tot)
+        HIPCHK(h, hipMemcpy(tot, h->planes[plane].tot.p, n4, hipMemcpyDeviceToHost));
+    if (toti) {
+        for (int t = 0; t < 6; t++) {
+            if (h->type_seen[t])
+                HIPCHK(h, hipMemcpy(toti + h->npix2 * t, h->planes[plane].toti[t].p, n4, hipMemcpyDeviceToHost));
+            else
+                memset(toti + h->npix2 * t, 0, n4);
+        }
+    }
+    if (nsel) {
+        unsigned long long c[6];
+        HIPCHK(h, hipMemcpy(c, h->d_counts + (size_t)plane * 6, sizeof c, hipMemcpyDeviceToHost));
+        for (int t = 0; t < 6; t++)
+            nsel[t] = (int64_t)c[t];
+    }
+    return SLICER_OK;
+}
+
+int slicer_device_malloc(slicer_handle h, size_t bytes, void **d_ptr)
+{
+    if (!h || !d_ptr)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(d_ptr, bytes));
+    return SLICER_OK;
+}
+
+int slicer_device_free(slicer_handle h, void *d_ptr)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    HIPCHK(h, hipFree(d_ptr));
+    return SLICER_OK;
+}
+
+int slicer_copy_to_device(slicer_handle h, void *d_dst, const void *src, size_t bytes)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    HIPCHK(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLICER_OK;
+}
+
+int slicer_copy_to_host(slicer_handle h, void *dst, const void *d_src, size_t bytes)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    HIPCHK(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLICER_OK;
+}
+
+int slicer_synth_positions(slicer_handle h, float *d_pos, uint64_t first, uint64_t count, double boxsize,
+                           uint64_t seed, int clustered)
+{
+    if (!h || (!d_pos && count))
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    ProfScope ps(h, KN_SYNTH);
+    HIPCHK(h, launch_synth(d_pos, first, count, boxsize, seed, clustered, h->stream));
+    return SLICER_OK;
+}
+
+int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t n, float *d_xs, float *d_ys,
+                         int32_t *d_plane, uint64_t *d_src, uint64_t capacity, uint64_t *n_out)
+{
+    int rc = check_deposit_args(h, type, d_pos, nullptr, n);
+    if (rc)
+        return rc;
+    PassParams P;
+    make_params(h, type, false, P);
+    unsigned long long *d_count = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_count, sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), h->stream));
+    {
+        ProfScope ps(h, KN_DEBUG);
+        HIPCHK(h, launch_debug_project(d_pos, n, P, d_xs, d_ys, d_plane, d_src, capacity, d_count, h->d_neg,
+                                       h->stream));
+    }
+    unsigned long long c = 0;
+    HIPCHK(h, hipMemcpyAsync(&c, d_count, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(d_count));
+    if (n_out)
+        *n_out = c;
+    return SLICER_OK;
+}
+
+int slicer_profile_enable(slicer_handle h, int on)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!on && h->profiling)
+        prof_collect(h);
+    h->profiling = on != 0;
+    return SLICER_OK;
+}
+
+int slicer_profile_reset(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    prof_collect(h);
+    for (int i = 0; i < KN_COUNT; i++) {
+        h->prof_ms[i] = 0;
+        h->prof_n[i] = 0;
+    }
+    return SLICER_OK;
+}
+
+int slicer_profile_get(slicer_handle h, slicer_kernel_time *out, int capacity, int *n_out)
+{
+    if (!h || !n_out)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    prof_collect(h);
+    int k = 0;
+    for (int i = 0; i < KN_COUNT; i++) {
+        if (!h->prof_n[i])
+            continue;
+        if (out && k < capacity) {
+            memset(&out[k], 0, sizeof out[k]);
+            strncpy(out[k].name, kKernelNames[i], sizeof(out[k].name) - 1);
+            out[k].launches = h->prof_n[i];
+            out[k].total_ms = h->prof_ms[i];
+        }
+        k++;
+    }
+    *n_out = k;
+    return SLICER_OK;
+}
+
+}  // extern "C"
