@@ -245,16 +245,19 @@ def test_tsc_multi_type_multi_file(S, algo):
     for accum in (slicer_amd.ACC_F32, slicer_amd.ACC_FIXED64):
         (tot, toti, cnt), = run_gpu(S, files, npix, fov, ld, ld2, accum=accum, algo=algo)
         assert np.array_equal(cnt, nsel)
+        # FIXED64 quantises every contribution at 2^-40 of the species' mass scale (<= 2): bitwise
+        # reproducible but accurate in the absolute sense, so pixels holding a single vanishing TSC weight
+        # (<< 1e-6 m) get an absolute slack; f32 / f64 accumulators keep the purely relative bar.
+        atol = 2.0 ** -29 if accum == slicer_amd.ACC_FIXED64 else 0.0
         for got, ref in [(tot, ref_tot)] + [(toti[t], ref_toti[t]) for t in range(6)]:
-            nz = ref > 0
-            assert np.array_equal(got == 0, ref == 0)
-            if nz.any():
-                rel = float((np.abs(got[nz].astype(np.float64) - ref[nz]) / ref[nz]).max())
-                assert rel < 3e-6, rel
+            if accum != slicer_amd.ACC_FIXED64:
+                assert np.array_equal(got == 0, ref == 0)
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            assert np.all(d <= 3e-6 * ref + atol), float((d - 3e-6 * ref).max())
         # shared accumulator (want_type_maps = 0) gives the same total within the same bar
         (tot2, _, _), = run_gpu(S, files, npix, fov, ld, ld2, accum=accum, algo=algo, want_type_maps=False)
-        nz = ref_tot > 0
-        assert float((np.abs(tot2[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max()) < 3e-6
+        d = np.abs(tot2.astype(np.float64) - ref_tot.astype(np.float64))
+        assert np.all(d <= 3e-6 * ref_tot + atol)
 
 
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
