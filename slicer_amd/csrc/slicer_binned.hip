@@ -1,0 +1,583 @@
+// slicer_binned.hip -- SLICER_ALGO_BINNED: project -> per-tile bins -> LDS-privatised tile deposit.
+//
+// Why: a TSC deposit is 9 read-modify-writes on a random pixel; as global float atomics that is
+// ~0.08 TB/s of added bytes on MI355X (64 lanes in 64 rows; MI355X_MICROARCH.md "Global float
+// atomics"), i.e. ~2e9 particles/s.  Here the scatter is done in LDS instead:
+//
+//   K1 k_project_bin   : stream raw POS (12 B/particle, dwordx4 loads), bit-faithful transform, slab
+//                        select; survivors are compacted through an LDS queue so that the fp64
+//                        sqrt/asin/atan2 run on full waves; emits (xs, ys) records + their tile bin,
+//                        a per-block histogram row and the block's record count.  No global atomics
+//                        on the data path.
+//   K2 k_scan_blocks / k_scan_bins : exclusive prefix over (bin-major, block-minor) -> every block's
+//                        write cursor for every bin (radix-partition style; no atomics).
+//   K3 k_bin_scatter   : moves each record to its bin's contiguous run (LDS cursors).
+//   K4 k_tile_deposit  : one workgroup per (plane, tile): tile + 1-pixel halo privatised in LDS,
+//                        ds_add_{f32,f64,u64,u32} per contribution, then one shaped (row-contiguous)
+//                        global atomic flush of the non-zero cells.
+//
+// Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
+#include "slicer_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace slicer {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kPerThread = 4;
+constexpr int kRound = kBlock * kPerThread;  // particles per round of one K1 block
+constexpr int kQCap = kRound + kBlock;       // LDS queue capacity (one round + carried remainder)
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// Reserve one slot per lane with pred set, one LDS atomic per wave.
+__device__ __forceinline__ unsigned wave_reserve(bool pred, unsigned *counter)
+{
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull)
+        return 0u;
+    unsigned lane = lane_id();
+    unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader)
+        base = atomicAdd(counter, (unsigned)__popcll(mask));
+    base = (unsigned)__shfl((int)base, leader);
+    return base + rank;
+}
+
+template <typename T>
+__device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// K1: project + bin
+// ---------------------------------------------------------------------------------------------
+template <int MAS, bool POW2, bool HAS_MASS, bool VEC>
+__global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
+                                                        uint64_t n, PassParams P, BinGeom G,
+                                                        float2 *__restrict__ cxy, unsigned *__restrict__ cbin,
+                                                        float *__restrict__ cm, unsigned *__restrict__ hist,
+                                                        unsigned *__restrict__ bcount, Targets T)
+{
+    extern __shared__ unsigned smem[];
+    unsigned *s_hist = smem;  // [nbins]
+    float *qx = reinterpret_cast<float *>(smem + G.nbins);
+    float *qy = qx + kQCap;
+    float *qz = qy + kQCap;
+    int *qp = reinterpret_cast<int *>(qz + kQCap);
+    float *qm = reinterpret_cast<float *>(qp + kQCap);  // only with HAS_MASS
+    __shared__ unsigned s_q, s_out, s_cnt[kMaxPlanes];
+    __shared__ int s_neg;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < G.nbins; i += kBlock)
+        s_hist[i] = 0;
+    if (tid < kMaxPlanes)
+        s_cnt[tid] = 0;
+    if (tid == 0) {
+        s_q = 0;
+        s_out = 0;
+        s_neg = 0;
+    }
+    __syncthreads();
+
+    const uint64_t b0 = (uint64_t)blockIdx.x * G.batch;
+    const uint64_t b1 = dmin<uint64_t>(n, b0 + G.batch);
+    bool neg = false;
+
+    for (uint64_t r0 = b0; r0 < b1; r0 += kRound) {
+        // ---- phase A: load 4 particles per thread, transform, slab select, enqueue survivors ----
+        const uint64_t i0 = r0 + (uint64_t)kPerThread * tid;
+        float rx[kPerThread], ry[kPerThread], rz[kPerThread], rm[kPerThread];
+        int nvalid = 0;
+        if (i0 < b1)
+            nvalid = (int)dmin<uint64_t>(kPerThread, b1 - i0);
+        if (VEC && nvalid == kPerThread) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
+            float4 a = p4[0], b = p4[1], c = p4[2];
+            rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
+            rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
+            rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
+            rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++) {
+                if (k < nvalid) {
+                    rx[k] = pos[3 * (i0 + k) + 0];
+                    ry[k] = pos[3 * (i0 + k) + 1];
+                    rz[k] = pos[3 * (i0 + k) + 2];
+                } else {
+                    rx[k] = ry[k] = rz[k] = 0.f;
+                }
+            }
+        }
+        if (HAS_MASS) {
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++)
+                rm[k] = k < nvalid ? mass[i0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            float x, y, z;
+            transform(rx[k], ry[k], rz[k], P, x, y, z);
+            const bool live = k < nvalid;
+            neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
+            int plane = -1;
+            for (int p = 0; p < P.n_planes; p++)
+                if (z >= P.zlo[p] && z < P.zhi[p])
+                    plane = p;  // slabs are disjoint on this path (checked on the host)
+            const bool sel = live && plane >= 0;
+            unsigned slot = wave_reserve(sel, &s_q);
+            if (sel) {
+                qx[slot] = x;
+                qy[slot] = y;
+                qz[slot] = z;
+                qp[slot] = plane;
+                if (HAS_MASS)
+                    qm[slot] = rm[k];
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: fp64 projection on dense groups of 256 queue entries ----
+        const unsigned q = s_q;
+        const bool last = r0 + kRound >= b1;
+        const unsigned nproc = last ? q : (q / kBlock) * kBlock;
+        for (unsigned g = 0; g < nproc; g += kBlock) {
+            const unsigned e = g + tid;
+            bool emit = false;
+            float xs = 0.f, ys = 0.f, m = 0.f;
+            unsigned bin = 0;
+            if (e < nproc) {
+                const int plane = qp[e];
+                if (project(qx[e], qy[e], qz[e], 0, 0, P, xs, ys)) {
+                    atomicAdd(&s_cnt[plane], 1u);
+                    int gx = grid_index<POW2>(xs, P);
+                    int gy = grid_index<POW2>(ys, P);
+                    const int nn = P.nn;
+                    if (MAS == kNGP) {
+                        emit = gx >= 0 && gx < nn && gy >= 0 && gy < nn;  // utilities.cpp:74 drop rule
+                    } else {
+                        emit = true;  // border-ring entries (g = -1 or nn) still feed the edge pixels
+                        gx = gx < 0 ? 0 : (gx >= nn ? nn - 1 : gx);
+                        gy = gy < 0 ? 0 : (gy >= nn ? nn - 1 : gy);
+                    }
+                    bin = (unsigned)plane * (unsigned)G.tiles_per_plane +
+                          (unsigned)(gy >> G.th_log2) * (unsigned)G.ntx + (unsigned)(gx >> G.tw_log2);
+                    if (HAS_MASS)
+                        m = qm[e];
+                }
+            }
+            unsigned o = wave_reserve(emit, &s_out);
+            if (emit) {
+                const uint64_t dst = b0 + o;
+                cxy[dst] = make_float2(xs, ys);
+                cbin[dst] = bin;
+                if (HAS_MASS)
+                    cm[dst] = m;
+                atomicAdd(&s_hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- carry the remainder (< 256 entries) to the queue front ----
+        const unsigned rem = q - nproc;
+        float tx = 0, ty = 0, tz = 0, tm = 0;
+        int tp = 0;
+        if ((unsigned)tid < rem) {
+            tx = qx[nproc + tid];
+            ty = qy[nproc + tid];
+            tz = qz[nproc + tid];
+            tp = qp[nproc + tid];
+            if (HAS_MASS)
+                tm = qm[nproc + tid];
+        }
+        __syncthreads();
+        if ((unsigned)tid < rem) {
+            qx[tid] = tx;
+            qy[tid] = ty;
+            qz[tid] = tz;
+            qp[tid] = tp;
+            if (HAS_MASS)
+                qm[tid] = tm;
+        }
+        if (tid == 0)
+            s_q = rem;
+        __syncthreads();
+    }
+
+    if (neg)
+        s_neg = 1;
+    __syncthreads();
+    unsigned *row = hist + (size_t)blockIdx.x * G.nbins;
+    for (int i = tid; i < G.nbins; i += kBlock)
+        row[i] = s_hist[i];
+    if (tid == 0) {
+        bcount[blockIdx.x] = s_out;
+        if (s_neg)
+            atomicOr(T.neg_flag, 1);
+    }
+    if (tid < P.n_planes && s_cnt[tid])
+        atomicAdd(T.nsel[tid], (unsigned long long)s_cnt[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: per bin, exclusive prefix over workgroups (in place) + total.  One 256-thread workgroup owns
+// 16 bins x 16 segments of the workgroup axis: segment sums, a 16-way scan in LDS, then the prefix write.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_blocks(unsigned *__restrict__ hist, unsigned *__restrict__ total,
+                                                     int nblocks, int nbins)
+{
+    __shared__ unsigned s_seg[16][17];
+    const int bl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int bin = blockIdx.x * 16 + bl;
+    const int per = (nblocks + 15) / 16;
+    const int lo = seg * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    unsigned sum = 0;
+    if (bin < nbins)
+        for (int b = lo; b < hi; b++)
+            sum += hist[(size_t)b * nbins + bin];
+    s_seg[seg][bl] = sum;
+    __syncthreads();
+    unsigned run = 0;
+    for (int k = 0; k < seg; k++)
+        run += s_seg[k][bl];
+    if (bin < nbins) {
+        for (int b = lo; b < hi; b++) {
+            const size_t i = (size_t)b * nbins + bin;
+            unsigned v = hist[i];
+            hist[i] = run;
+            run += v;
+        }
+        if (seg == 15)
+            total[bin] = run;
+    }
+}
+
+// K2b: exclusive scan over bins (single workgroup), base[nbins] = total record count
+__global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__ total, unsigned *__restrict__ base,
+                                                    int nbins)
+{
+    __shared__ unsigned s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nbins + 1023) / 1024;
+    const int lo = tid * per;
+    unsigned sum = 0;
+    for (int i = lo; i < lo + per && i < nbins; i++)
+        sum += total[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = tid ? s_part[tid - 1] : 0;
+    for (int i = lo; i < lo + per && i < nbins; i++) {
+        base[i] = run;
+        run += total[i];
+    }
+    if (tid == 1023)
+        base[nbins] = s_part[1023];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: scatter records into their bin runs
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_MASS>
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict__ cxy, const unsigned *__restrict__ cbin,
+                                                        const float *__restrict__ cm,
+                                                        const unsigned *__restrict__ prefix,
+                                                        const unsigned *__restrict__ base,
+                                                        const unsigned *__restrict__ bcount, int nblocks, BinGeom G,
+                                                        float2 *__restrict__ sxy, float *__restrict__ sm)
+{
+    extern __shared__ unsigned s_off[];
+    const int tid = threadIdx.x;
+    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, and inside a bin
+    // the runs of consecutive K1 workgroups are adjacent in memory.  Giving each XCD a contiguous range of
+    // K1 workgroups lets its L2 merge the neighbouring short runs into whole lines before write-back.
+    const int per_xcd = (nblocks + 7) / 8;
+    const int lb = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lb >= nblocks || (int)(blockIdx.x >> 3) >= per_xcd)
+        return;
+    const unsigned *row = prefix + (size_t)lb * G.nbins;
+    for (int i = tid; i < G.nbins; i += kBlock)
+        s_off[i] = base[i] + row[i];
+    __syncthreads();
+    const unsigned count = bcount[lb];
+    const uint64_t b0 = (uint64_t)lb * G.batch;
+    // U independent loads in flight per lane: the loop is otherwise bound by one load latency per record
+    constexpr int U = 8;
+    for (unsigned i0 = 0; i0 < count; i0 += U * kBlock) {
+        unsigned bin[U];
+        float2 xy[U];
+        float m[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned i = i0 + u * kBlock + tid;
+            if (i < count) {
+                bin[u] = cbin[b0 + i];
+                xy[u] = cxy[b0 + i];
+                if (HAS_MASS)
+                    m[u] = cm[b0 + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned i = i0 + u * kBlock + tid;
+            if (i < count) {
+                const unsigned dst = atomicAdd(&s_off[bin[u]], 1u);
+                sxy[dst] = xy[u];
+                if (HAS_MASS)
+                    sm[dst] = m[u];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: LDS-privatised tile deposit
+// ---------------------------------------------------------------------------------------------
+// Global accumulator type of each mode, and the type of the LDS tile cell.  Measured on MI355X
+// (tools/lds_atomic_bench.hip, 3x3 random cells of a 130x130 tile, 512-thread workgroups):
+//   ds_add_f32 0.20 T lane-ops/s   ds_add_f64 1.81 T   ds_add_u64 3.51 T   ds_add_u32 6.61 T
+// ds_add_f32 is 9x slower than ds_add_f64, so no mode keeps f32 cells in LDS: f32/f64 modes sum the
+// tile in f64 (and round once per flush), fixed point in u64, NGP counts in u32.
+template <int ACC> struct AccT { using type = float; using lds = double; };
+template <> struct AccT<kF64> { using type = double; using lds = double; };
+template <> struct AccT<kFixed64> { using type = unsigned long long; using lds = unsigned long long; };
+template <> struct AccT<kCountU32> { using type = unsigned; using lds = unsigned; };
+
+template <int ACC>
+__device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, const PassParams &P)
+{
+    if (ACC == kF32 || ACC == kF64)
+        atomicAdd(reinterpret_cast<double *>(cell), (double)c);  // ds_add_f64
+    else if (ACC == kFixed64)
+        atomicAdd(reinterpret_cast<unsigned long long *>(cell),
+                  (unsigned long long)__double2ll_rn((double)c * P.fixed_scale));  // ds_add_u64
+}
+
+constexpr int kTileBlock = 512;
+
+template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T)
+{
+    using acc_t = typename AccT<ACC>::type;
+    using lds_t = typename AccT<ACC>::lds;
+    extern __shared__ unsigned char smem_raw[];
+    lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
+
+    const unsigned bin = blockIdx.x;
+    unsigned nrec = 0;
+    for (int c = 0; c < L.n; c++)
+        nrec += L.base[c][bin + 1] - L.base[c][bin];
+    if (nrec == 0)
+        return;
+    const int plane = bin / G.tiles_per_plane;
+    const int t = bin % G.tiles_per_plane;
+    const int x0 = (t % G.ntx) << G.tw_log2;
+    const int y0 = (t / G.ntx) << G.th_log2;
+    const int W = (1 << G.tw_log2) + 2, H = (1 << G.th_log2) + 2;
+    const int cells = W * H;
+    const int tid = threadIdx.x;
+    const int nn = P.nn;
+
+    for (int i = tid; i < cells; i += kTileBlock)
+        tile[i] = (lds_t)0;
+    __syncthreads();
+
+    constexpr int U = 4;  // records in flight per lane
+    for (int c = 0; c < L.n; c++) {
+        const unsigned start = L.base[c][bin], end = L.base[c][bin + 1];
+        const float2 *__restrict__ sxy = L.sxy[c];
+        const float *__restrict__ sm = L.sm[c];
+        const float mconst = L.mconst[c], smc = L.sm_const[c];
+        for (unsigned i0 = start; i0 < end; i0 += U * kTileBlock) {
+            float2 r[U];
+            float mr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned i = i0 + u * kTileBlock + tid;
+                if (i < end) {
+                    r[u] = sxy[i];
+                    if (HAS_MASS)
+                        mr[u] = sm[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned i = i0 + u * kTileBlock + tid;
+                if (i >= end)
+                    continue;
+                const float xs = r[u].x, ys = r[u].y;
+                float m = mconst, sq = smc;
+                if (HAS_MASS) {
+                    m = cap_mass(mr[u]);
+                    sq = __fsqrt_rn(m);
+                }
+                const int gx = grid_index<POW2>(xs, P);
+                const int gy = grid_index<POW2>(ys, P);
+                if (MAS == kNGP) {
+                    lds_t *cell = tile + (gy - y0 + 1) * W + (gx - x0 + 1);
+                    if (ACC == kCountU32)
+                        atomicAdd(reinterpret_cast<unsigned *>(cell), 1u);
+                    else
+                        atomicAdd(reinterpret_cast<double *>(cell), (double)m);
+                } else {
+                    float wx[3], wy[3];
+                    tsc_axis<POW2>(xs, gx, P, wx);
+                    tsc_axis<POW2>(ys, gy, P, wy);
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        wx[a] = sq * wx[a];
+                        wy[a] = sq * wy[a];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const int py = gy + b - 1;
+                        if (py < 0 || py >= nn)
+                            continue;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const int px = gx + a - 1;
+                            if (px < 0 || px >= nn)
+                                continue;
+                            lds_add<ACC>(tile + (py - y0 + 1) * W + (px - x0 + 1), wx[a] * wy[b], P);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
+    acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
+    for (int i = tid; i < cells; i += kTileBlock) {
+        const lds_t v = tile[i];
+        if (v == (lds_t)0)
+            continue;
+        const int py = y0 - 1 + i / W;
+        const int px = x0 - 1 + i % W;
+        if (px < 0 || px >= nn || py < 0 || py >= nn)
+            continue;
+        atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
+{
+    return sizeof(unsigned) * (size_t)G.nbins + (size_t)kQCap * (has_mass ? 20 : 16);
+}
+
+template <int MAS, bool POW2, bool HAS_MASS>
+static hipError_t launch_k1(bool vec, const float *pos, const float *mass, uint64_t n, const PassParams &P,
+                            const BinGeom &G, const BinWorkspace &W, const Targets &T, hipStream_t s)
+{
+    const int nb = (int)((n + G.batch - 1) / G.batch);
+    const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
+    if (vec)
+        k_project_bin<MAS, POW2, HAS_MASS, true><<<nb, kBlock, lds, s>>>(pos, mass, n, P, G, W.cxy, W.cbin, W.cm,
+                                                                         W.hist, W.bcount, T);
+    else
+        k_project_bin<MAS, POW2, HAS_MASS, false><<<nb, kBlock, lds, s>>>(pos, mass, n, P, G, W.cxy, W.cbin, W.cm,
+                                                                          W.hist, W.bcount, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
+                              const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
+                              hipStream_t s)
+{
+    const bool vec = (reinterpret_cast<uintptr_t>(d_pos) & 15u) == 0;
+    const bool pow2 = P.pow2 != 0;
+#define K1(MAS_, P2_, HM_) launch_k1<MAS_, P2_, HM_>(vec, d_pos, d_mass, n, P, G, W, T, s)
+    if (cfg.mas == kNGP) {
+        if (pow2)
+            return cfg.has_mass ? K1(kNGP, true, true) : K1(kNGP, true, false);
+        return cfg.has_mass ? K1(kNGP, false, true) : K1(kNGP, false, false);
+    }
+    if (pow2)
+        return cfg.has_mass ? K1(kTSC, true, true) : K1(kTSC, true, false);
+    return cfg.has_mass ? K1(kTSC, false, true) : K1(kTSC, false, false);
+#undef K1
+}
+
+hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+{
+    k_scan_blocks<<<(G.nbins + 15) / 16, 256, 0, s>>>(W.hist, W.total, nblocks, G.nbins);
+    k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+{
+    const size_t lds = sizeof(unsigned) * (size_t)G.nbins;
+    const int grid = 8 * ((nblocks + 7) / 8);
+    if (has_mass)
+        k_bin_scatter<true><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+                                                      W.sm);
+    else
+        k_bin_scatter<false><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+                                                       W.sm);
+    return hipGetLastError();
+}
+
+size_t tile_lds_bytes(const BinGeom &G, int acc)
+{
+    const size_t elem = acc == kCountU32 ? 4 : 8;
+    return elem * (size_t)((1 << G.tw_log2) + 2) * (size_t)((1 << G.th_log2) + 2);
+}
+
+template <int MAS, int ACC>
+static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const BinGeom &G, const PendingList &L,
+                            const Targets &T, hipStream_t s)
+{
+    const size_t lds = tile_lds_bytes(G, ACC);
+#define K4(P2_, HM_)                                                                                             \
+    do {                                                                                                         \
+        auto kern = k_tile_deposit<MAS, ACC, P2_, HM_>;                                                          \
+        if (lds > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            if (e != hipSuccess)                                                                                 \
+                return e;                                                                                        \
+        }                                                                                                        \
+        kern<<<G.nbins, kTileBlock, lds, s>>>(L, P, G, T);                                         \
+    } while (0)
+    if (pow2) {
+        if (has_mass) K4(true, true); else K4(true, false);
+    } else {
+        if (has_mass) K4(false, true); else K4(false, false);
+    }
+#undef K4
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
+                               const Targets &T, hipStream_t s)
+{
+    const bool pow2 = P.pow2 != 0;
+    if (cfg.mas == kNGP) {
+        if (cfg.acc == kCountU32)
+            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, s);
+        return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, s);
+    }
+    switch (cfg.acc) {
+    case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, s);
+    case kF64: return launch_k4<kTSC, kF64>(pow2, cfg.has_mass, P, G, L, T, s);
+    case kFixed64: return launch_k4<kTSC, kFixed64>(pow2, cfg.has_mass, P, G, L, T, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace slicer

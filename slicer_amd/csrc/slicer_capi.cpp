@@ -72,6 +72,17 @@ struct slicer_handle_s {
     hipEvent_t stage_free[2] = {nullptr, nullptr};
     uint64_t stage_cap = 0;  // particles
 
+    // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
+    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_total, w_bcount;
+    DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
+    // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
+    PendingList pend{};
+    int pend_key = -1;  // type * 2 + has_mass (or 12 + has_mass for the shared accumulator)
+    LaunchCfg pend_cfg{};
+    PassParams pend_P{};
+    BinGeom pend_G{};
+    Targets pend_T{};
+
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -334,6 +345,80 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
     T.neg_flag = h->d_neg;
 }
 
+constexpr int kBinBatch = 16384;  // particles per K1 workgroup
+constexpr int kMaxBins = 8192;    // LDS histogram / cursor table: 32 KiB
+
+// Tile geometry of the binned path.  Tiles are powers of two so that pixel -> tile is a shift.  4-byte
+// LDS cells (NGP counts): up to 128 x 128 (+halo = 67.6 KiB of LDS, two workgroups per CU); 8-byte: 64 x 128.
+// Small maps get smaller tiles so that the grid still has >= ~1024 workgroups.
+bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
+{
+    for (int p = 0; p < d.n_planes; p++)
+        if (d.nrepperp[p] != 0)
+            return false;
+    for (int p = 0; p < d.n_planes; p++)  // slabs must be disjoint: a particle enters at most one bin
+        for (int q = p + 1; q < d.n_planes; q++)
+            if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
+                return false;
+    const bool wide = acc != kCountU32;  // every mode but the NGP counts keeps 8-byte cells in LDS
+    int s = 7;  // log2 tile side
+    auto tiles = [&](int sl) {
+        int tw = 1 << sl, th = 1 << (wide ? sl - 1 : sl);
+        return (long)((d.npix + tw - 1) / tw) * (long)((d.npix + th - 1) / th);
+    };
+    while (s > 4 && tiles(s) * d.n_planes < 1024)
+        s--;
+    G.tw_log2 = s;
+    G.th_log2 = wide ? s - 1 : s;
+    G.ntx = (d.npix + (1 << G.tw_log2) - 1) >> G.tw_log2;
+    G.nty = (d.npix + (1 << G.th_log2) - 1) >> G.th_log2;
+    G.tiles_per_plane = G.ntx * G.nty;
+    long nb = (long)G.tiles_per_plane * d.n_planes;
+    if (nb > kMaxBins)
+        return false;
+    G.nbins = (int)nb;
+    G.batch = kBinBatch;
+    return true;
+}
+
+int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, BinWorkspace &W)
+{
+    const uint64_t cap = h->max_chunk;
+    const uint64_t nbmax = (cap + kBinBatch - 1) / kBinBatch;
+    int rc;
+    if ((rc = ensure(h, h->w_cxy, cap * 8)) || (rc = ensure(h, h->w_cbin, cap * 4)) ||
+        (rc = ensure(h, h->w_hist, nbmax * kMaxBins * 4)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
+        (rc = ensure(h, h->w_bcount, nbmax * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
+        (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
+        return rc;
+    if (has_mass && ((rc = ensure(h, h->w_cm, cap * 4)) || (rc = ensure(h, h->w_sm[slot], n * 4))))
+        return rc;
+    W.cxy = (float2 *)h->w_cxy.p;
+    W.cbin = (unsigned *)h->w_cbin.p;
+    W.cm = (float *)h->w_cm.p;
+    W.sxy = (float2 *)h->w_sxy[slot].p;
+    W.sm = (float *)h->w_sm[slot].p;
+    W.hist = (unsigned *)h->w_hist.p;
+    W.total = (unsigned *)h->w_total.p;
+    W.base = (unsigned *)h->w_base[slot].p;
+    W.bcount = (unsigned *)h->w_bcount.p;
+    return SLICER_OK;
+}
+
+// Deposit every pending (binned) chunk with one tile-kernel launch.
+int flush_pending(slicer_handle h)
+{
+    if (h->pend.n == 0)
+        return SLICER_OK;
+    {
+        ProfScope ps(h, KN_TILE);
+        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, h->stream));
+    }
+    h->pend.n = 0;
+    h->pend_key = -1;
+    return SLICER_OK;
+}
+
 int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n)
 {
     const slicer_plane_desc &d = h->desc;
@@ -343,10 +428,50 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     Targets T;
     fill_targets(h, type, has_mass, T);
     LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
-    {
+    BinGeom G;
+    bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G);
+    if (binned && d.algo == SLICER_ALGO_AUTO && n < 65536)
+        binned = false;  // several launches are not worth it for a tiny chunk
+    if (!binned) {
         ProfScope ps(h, KN_DIRECT);
         HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
+        return SLICER_OK;
     }
+    const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
+    const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
+    int rc;
+    if (h->pend.n && (h->pend_key != key || h->pend.n == kMaxPending) && (rc = flush_pending(h)))
+        return rc;
+    const int slot = h->pend.n;
+    BinWorkspace W;
+    if ((rc = ensure_bin_workspace(h, has_mass, slot, n, W)))
+        return rc;
+    const int nblocks = (int)((n + G.batch - 1) / G.batch);
+    {
+        ProfScope ps(h, KN_PROJECT);
+        HIPCHK(h, launch_project_bin(cfg, d_pos, d_mass, n, P, G, W, T, h->stream));
+    }
+    {
+        ProfScope ps(h, KN_SCAN);
+        HIPCHK(h, launch_bin_scan(nblocks, G, W, h->stream));
+    }
+    {
+        ProfScope ps(h, KN_SCATTER);
+        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, G, W, h->stream));
+    }
+    if (slot == 0) {
+        h->pend_key = key;
+        h->pend_cfg = cfg;
+        h->pend_P = P;
+        h->pend_G = G;
+        h->pend_T = T;
+    }
+    h->pend.sxy[slot] = W.sxy;
+    h->pend.sm[slot] = has_mass ? W.sm : nullptr;
+    h->pend.base[slot] = W.base;
+    h->pend.mconst[slot] = P.mconst;
+    h->pend.sm_const[slot] = P.sm_const;
+    h->pend.n = slot + 1;
     return SLICER_OK;
 }
 
@@ -467,6 +592,13 @@ int slicer_destroy(slicer_handle h)
             release(pl.acc[t]);
         }
     }
+    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_total, &h->w_bcount})
+        release(*b);
+    for (int i = 0; i < kMaxPending; i++) {
+        release(h->w_sxy[i]);
+        release(h->w_sm[i]);
+        release(h->w_base[i]);
+    }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->d_stage[i]) (void)hipFree(h->d_stage[i]);
@@ -521,6 +653,8 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     h->finalized = false;
     h->shared_seen = false;
     h->fixed_shared_set = false;
+    h->pend.n = 0;
+    h->pend_key = -1;
     for (int t = 0; t < 6; t++) {
         h->type_seen[t] = false;
         h->fixed_exp_set[t] = false;
@@ -625,6 +759,10 @@ int slicer_file_end(slicer_handle h)
         return fail(h, SLICER_ERR_STATE, "slicer_file_end without slicer_file_begin");
     h->in_file = false;
     if (h->desc.mas == SLICER_MAS_NGP) {
+        // the per-file fold needs this file's complete counts
+        int rcf = flush_pending(h);
+        if (rcf)
+            return rcf;
         bool any = false;
         for (int t = 0; t < 6; t++)
             any |= h->file_mode[t] != 0;
@@ -659,6 +797,11 @@ int slicer_plane_finalize(slicer_handle h)
     if (h->finalized)
         return SLICER_OK;
     const slicer_plane_desc &d = h->desc;
+    {
+        int rcf = flush_pending(h);
+        if (rcf)
+            return rcf;
+    }
     if (d.mas == SLICER_MAS_TSC) {
         const int kind = acc_kind(d, false);
         for (int p = 0; p < d.n_planes; p++) {

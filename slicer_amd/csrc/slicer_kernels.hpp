@@ -57,4 +57,46 @@ hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams
                                 int32_t *d_plane, uint64_t *d_src, uint64_t capacity, unsigned long long *d_count,
                                 int *neg_flag, hipStream_t s);
 
+// ---- SLICER_ALGO_BINNED (slicer_binned.hip) ----
+struct BinGeom {
+    int tw_log2, th_log2;  // tile width / height in pixels (powers of two)
+    int ntx, nty;          // tiles per map row / column
+    int tiles_per_plane;
+    int nbins;             // n_planes * tiles_per_plane
+    int batch;             // particles per K1 workgroup (= size of its region in the compact buffer)
+};
+
+struct BinWorkspace {
+    float2 *cxy;       // [max_chunk] compact (xs, ys), workgroup b owns [b*batch, b*batch + bcount[b])
+    unsigned *cbin;    // [max_chunk] bin of each compact record
+    float *cm;         // [max_chunk] per-particle mass (hydro) or nullptr
+    float2 *sxy;       // [max_chunk] records grouped by bin
+    float *sm;         // [max_chunk] or nullptr
+    unsigned *hist;    // [nblocks][nbins] per-workgroup histogram, scanned in place
+    unsigned *total;   // [nbins]
+    unsigned *base;    // [nbins + 1] start of every bin's run in sxy
+    unsigned *bcount;  // [nblocks]
+};
+
+size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
+size_t tile_lds_bytes(const BinGeom &G, int acc);
+hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
+                              const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
+                              hipStream_t s);
+hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
+// Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
+// LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
+constexpr int kMaxPending = 8;
+struct PendingList {
+    int n;
+    const float2 *sxy[kMaxPending];
+    const float *sm[kMaxPending];
+    const unsigned *base[kMaxPending];
+    float mconst[kMaxPending];    // (float)massarr[t] of the chunk's file
+    float sm_const[kMaxPending];  // sqrtf(mconst)
+};
+hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
+                               const Targets &T, hipStream_t s);
+
 }  // namespace slicer
