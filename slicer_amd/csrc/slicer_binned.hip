@@ -17,6 +17,8 @@
 //                        global atomic flush of the non-zero cells.
 //
 // Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
+#include <cstdlib>
+
 #include "slicer_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict
                                                         const unsigned *__restrict__ prefix,
                                                         const unsigned *__restrict__ base,
                                                         const unsigned *__restrict__ bcount, int nblocks, BinGeom G,
-                                                        float2 *__restrict__ sxy, float *__restrict__ sm)
+                                                        float2 *__restrict__ sxy, float *__restrict__ sm, int dbg)
 {
     extern __shared__ unsigned s_off[];
     const int tid = threadIdx.x;
@@ -331,7 +333,14 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict
         for (int u = 0; u < U; u++) {
             const unsigned i = i0 + u * kBlock + tid;
             if (i < count) {
-                const unsigned dst = atomicAdd(&s_off[bin[u]], 1u);
+                unsigned dst = atomicAdd(&s_off[bin[u]], 1u);
+                if (dbg == 1) {  // experiment: no scattered store
+                    if (dst == 0xFFFFFFFFu)
+                        sxy[0] = xy[u];
+                    continue;
+                }
+                if (dbg == 2)  // experiment: coalesced store
+                    dst = (unsigned)(b0 + i);
                 sxy[dst] = xy[u];
                 if (HAS_MASS)
                     sm[dst] = m[u];
@@ -363,7 +372,7 @@ __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, 
                   (unsigned long long)__double2ll_rn((double)c * P.fixed_scale));  // ds_add_u64
 }
 
-constexpr int kTileBlock = 512;
+constexpr int kTileBlock = 1024;
 
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T)
@@ -523,12 +532,13 @@ hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, cons
 {
     const size_t lds = sizeof(unsigned) * (size_t)G.nbins;
     const int grid = 8 * ((nblocks + 7) / 8);
+    static const int dbg = getenv("SLICER_DBG_SCATTER") ? atoi(getenv("SLICER_DBG_SCATTER")) : 0;
     if (has_mass)
         k_bin_scatter<true><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                      W.sm);
+                                                      W.sm, dbg);
     else
         k_bin_scatter<false><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                       W.sm);
+                                                       W.sm, dbg);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -345,7 +346,7 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
     T.neg_flag = h->d_neg;
 }
 
-constexpr int kBinBatch = 16384;  // particles per K1 workgroup
+constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
 constexpr int kMaxBins = 8192;    // LDS histogram / cursor table: 32 KiB
 
 // Tile geometry of the binned path.  Tiles are powers of two so that pixel -> tile is a shift.  4-byte
@@ -360,6 +361,9 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
         for (int q = p + 1; q < d.n_planes; q++)
             if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
                 return false;
+    static const int env_s = getenv("SLICER_TILE_LOG2") ? atoi(getenv("SLICER_TILE_LOG2")) : 0;
+    static const int env_h = getenv("SLICER_TILE_H_LOG2") ? atoi(getenv("SLICER_TILE_H_LOG2")) : 0;
+    static const int env_b = getenv("SLICER_BIN_BATCH") ? atoi(getenv("SLICER_BIN_BATCH")) : 0;
     const bool wide = acc != kCountU32;  // every mode but the NGP counts keeps 8-byte cells in LDS
     int s = 7;  // log2 tile side
     auto tiles = [&](int sl) {
@@ -370,6 +374,10 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
         s--;
     G.tw_log2 = s;
     G.th_log2 = wide ? s - 1 : s;
+    if (env_s) {
+        G.tw_log2 = env_s;
+        G.th_log2 = env_h ? env_h : env_s;
+    }
     G.ntx = (d.npix + (1 << G.tw_log2) - 1) >> G.tw_log2;
     G.nty = (d.npix + (1 << G.th_log2) - 1) >> G.th_log2;
     G.tiles_per_plane = G.ntx * G.nty;
@@ -377,14 +385,14 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     if (nb > kMaxBins)
         return false;
     G.nbins = (int)nb;
-    G.batch = kBinBatch;
+    G.batch = env_b ? env_b : kBinBatch;
     return true;
 }
 
 int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, BinWorkspace &W)
 {
     const uint64_t cap = h->max_chunk;
-    const uint64_t nbmax = (cap + kBinBatch - 1) / kBinBatch;
+    const uint64_t nbmax = (cap + 4096 - 1) / 4096;
     int rc;
     if ((rc = ensure(h, h->w_cxy, cap * 8)) || (rc = ensure(h, h->w_cbin, cap * 4)) ||
         (rc = ensure(h, h->w_hist, nbmax * kMaxBins * 4)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
