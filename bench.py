@@ -17,7 +17,6 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -50,7 +49,7 @@ def parse():
     ap.add_argument("--clustered", action="store_true")
     ap.add_argument("--shard", default="snapshots", choices=["snapshots", "files"])
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
-    ap.add_argument("--cpu-particles", type=int, default=1 << 22, help="particles per CPU-baseline worker file")
+    ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=2)
     return ap.parse_args()
@@ -115,6 +114,7 @@ def main():
     import torch.distributed as dist
 
     import slicer_amd
+    from slicer_amd import parallel
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -145,8 +145,7 @@ def main():
     else:
         my_snaps = list(range(a.snapshots))
         seed0 = 0x51CE2                         # same boxes everywhere, sub-files split as slicer-v2.cpp:162-175
-        intdiv, rem = files // world, files % world
-        lo, hi = rank * intdiv, (rank + 1) * intdiv + (rem if rank == world - 1 else 0)
+        lo, hi = parallel.file_range(files, world, rank)
         my_files = list(range(lo, hi))
 
     # resident raw POS blocks: [snapshot][file] -> torch buffer (HBM)
@@ -160,10 +159,6 @@ def main():
         pos.append(row)
     torch.cuda.synchronize()
 
-    recv = None
-    if a.shard == "files" and world > 1:
-        recv = [torch.empty(a.npix * a.npix, dtype=torch.float32, device="cuda") for _ in lds] if rank == 0 else None
-
     def step(i):
         s = i % len(my_snaps)
         S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False)
@@ -175,10 +170,7 @@ def main():
         S.plane_finalize()
         if a.shard == "files" and world > 1:
             # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL reduce over xGMI
-            for p in range(len(lds)):
-                d_tot, _ = S.plane_device_maps(p)
-                t = _as_tensor(torch, d_tot, a.npix * a.npix)
-                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            parallel.reduce_planes(S, dist, torch, root=0, per_type=False)
 
     # deposits per step (identical for a given snapshot every time it is processed)
     dep_per_snap = []
@@ -294,15 +286,6 @@ def _counts(S, plane):
     if rc:
         raise RuntimeError(f"slicer_plane_read failed: {rc}")
     return nsel
-
-
-def _as_tensor(torch, ptr, n):
-    """Wrap a device pointer owned by the slicer handle as a torch tensor (no copy) for torch.distributed."""
-    class _Iface:
-        pass
-    o = _Iface()
-    o.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
-    return torch.as_tensor(o, device="cuda")
 
 
 if __name__ == "__main__":

@@ -136,6 +136,11 @@ int slicer_plane_device_maps(slicer_handle h, int plane, float **d_tot, float **
  * is always 0 because of the shadowed array at densitymaps.cpp:497) or NULL. */
 int slicer_plane_read(slicer_handle h, int plane, float *tot, float *toti, int64_t *nsel);
 int slicer_synchronize(slicer_handle h);
+/* the hipStream_t all work of this handle is enqueued on, and the device array of selected-entry counters
+ * of `plane` (6 x uint64), for callers that reduce across ranks themselves (slicer_amd_rccl.h) */
+int slicer_get_stream(slicer_handle h, void **hip_stream);
+int slicer_plane_info(slicer_handle h, int32_t *npix, int32_t *n_planes); /* of the current plane pass */
+int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
 
 /* --- utilities for benches and tests (device-side synthetic boxes) --- */
 int slicer_device_malloc(slicer_handle h, size_t bytes, void **d_ptr);

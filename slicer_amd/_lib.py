@@ -43,6 +43,9 @@ SYMBOLS = {
     "slicer_plane_device_maps": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "slicer_plane_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "slicer_synchronize": (C.c_int, [_H]),
+    "slicer_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
+    "slicer_plane_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "slicer_plane_device_counts": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "slicer_device_malloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "slicer_device_free": (C.c_int, [_H, C.c_void_p]),
     "slicer_copy_to_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t]),

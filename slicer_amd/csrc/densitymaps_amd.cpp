@@ -1,0 +1,180 @@
+// densitymaps_amd.cpp -- createDensityMaps (densitymaps.cpp:419-524) over the C ABI of include/slicer_amd.h.
+// Host orchestration only; every particle goes through libslicer_amd.so's HIP kernels.
+#include "densitymaps_amd.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "../../include/slicer_amd.h"
+#include "gadget2_reader.hpp"
+
+namespace {
+
+struct AdapterState {
+    slicer_handle h = nullptr;
+    int device = -1;
+    int mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32, algo = SLICER_ALGO_AUTO, true_counts = 0;
+    int want_device = -1;
+};
+AdapterState g;
+
+int env_int(const char *k, int dflt)
+{
+    const char *v = getenv(k);
+    return v ? atoi(v) : dflt;
+}
+
+bool ensure_handle(int myid)
+{
+    if (g.h)
+        return true;
+    int dev = g.want_device >= 0 ? g.want_device : env_int("SLICER_AMD_DEVICE", -1);
+    if (dev < 0) {
+        int ndev = env_int("SLICER_AMD_NUM_DEVICES", 1);  // one MPI rank per GPU: rank -> device
+        dev = ndev > 0 ? myid % ndev : 0;
+    }
+    const uint64_t chunk = (uint64_t)env_int("SLICER_AMD_CHUNK_LOG2", 24);
+    int rc = slicer_create(dev, 1ull << chunk, &g.h);
+    if (rc != SLICER_OK) {
+        std::cerr << "slicer_amd: " << slicer_last_error(nullptr) << std::endl;
+        g.h = nullptr;
+        return false;
+    }
+    g.device = dev;
+    g.mas = env_int("SLICER_AMD_NGP", g.mas == SLICER_MAS_NGP) ? SLICER_MAS_NGP : SLICER_MAS_TSC;
+    return true;
+}
+
+}  // namespace
+
+extern "C" void slicer_amd_adapter_config(int mas, int accum, int algo, int true_counts, int device)
+{
+    g.mas = mas;
+    g.accum = accum;
+    g.algo = algo;
+    g.true_counts = true_counts;
+    g.want_device = device;
+}
+
+extern "C" void slicer_amd_adapter_shutdown(void)
+{
+    if (g.h)
+        slicer_destroy(g.h);
+    g.h = nullptr;
+}
+
+int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, unsigned int ffmin, unsigned int ffmax,
+                      std::string File, double fovradiants, double rcase, gsl_spline *, gsl_interp_accel *,
+                      gsl_spline *, gsl_interp_accel *, std::valarray<float> &mapxytot,
+                      std::valarray<float> (&mapxytoti)[6], int (&ntotxyi)[6], int myid)
+{
+    const size_t np2 = (size_t)p.npix * (size_t)p.npix;
+    mapxytot.resize(np2);  // densitymaps.cpp:426-431 (valarray::resize zero-fills)
+    for (int i = 0; i < 6; i++) {
+        ntotxyi[i] = 0;
+        mapxytoti[i].resize(np2);
+    }
+    if (!ensure_handle(myid))
+        return 1;
+    slicer_handle h = g.h;
+
+    slicer_plane_desc d{};
+    d.npix = p.npix;
+    d.n_planes = 1;
+    d.mas = g.mas;
+    d.accum = g.accum;
+    d.algo = g.algo;
+    d.hydro = p.hydro ? 1 : 0;
+    d.snopt = p.snopt;
+    d.want_type_maps = 1;
+    d.fov_rad = fovradiants;
+    d.ld[0] = lens.ld[isnap];
+    d.ld2[0] = lens.ld2[isnap];
+    d.nrepperp[0] = lens.nrepperp[isnap];
+    if (slicer_plane_begin(h, &d) != SLICER_OK) {
+        std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+        return 1;
+    }
+
+    for (unsigned int ff = ffmin; ff < ffmax; ff++) {
+        char suffix[32];
+        snprintf(suffix, sizeof suffix, "%i", (int)ff);  // sconv(ff, fINT)
+        const std::string file_in = File + "." + suffix;
+        slicer_amd::SnapshotFile snap;
+        if (!snap.open(file_in)) {
+            std::cerr << "Error in opening the file: " << file_in << "!\n\a";  // gadget2io.cpp:20
+            return 1;
+        }
+        const Header &data = snap.header();
+        std::vector<float> pos;
+        if (!snap.read_block("POS ", pos)) {
+            std::cerr << "slicer_amd: no POS block in " << snap.path() << std::endl;
+            return 1;
+        }
+        std::vector<float> mass[6];
+        if (p.hydro && !snap.read_masses(mass)) {
+            std::cerr << "slicer_amd: cannot read MASS/BHMA in " << snap.path() << std::endl;
+            return 1;
+        }
+        slicer_file_desc f{};
+        size_t ntot = 0;
+        for (int t = 0; t < 6; t++) {
+            f.npart[t] = data.npart[t];
+            f.massarr[t] = data.massarr[t];
+            ntot += data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
+        }
+        if (pos.size() < 3 * ntot) {
+            std::cerr << "slicer_amd: POS block of " << snap.path() << " is shorter than the header says" << std::endl;
+            return 1;
+        }
+        f.boxsize = data.boxsize;
+        f.sgn[0] = random.sgnX[isnap];
+        f.sgn[1] = random.sgnY[isnap];
+        f.sgn[2] = random.sgnZ[isnap];
+        f.face = random.face[isnap];
+        f.center[0] = random.x0[isnap];
+        f.center[1] = random.y0[isnap];
+        f.center[2] = random.z0[isnap];
+        f.rcase = (float)rcase;  // readPos takes "float rcase" (gadget2io.h:122)
+        if (slicer_file_begin(h, &f) != SLICER_OK) {
+            std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+            return 1;
+        }
+        size_t off = 0;
+        for (int t = 0; t < 6; t++) {
+            const size_t n = data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
+            if (n) {
+                const float *m = (p.hydro && data.massarr[t] == 0 && !mass[t].empty()) ? mass[t].data() : nullptr;
+                if (slicer_deposit_host(h, t, pos.data() + 3 * off, m, n) != SLICER_OK) {
+                    std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+                    return 1;
+                }
+            }
+            off += n;
+        }
+        if (slicer_file_end(h) != SLICER_OK) {
+            std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+            return 1;
+        }
+        if (myid == 0)
+            std::cout << " done map*tot " << std::endl;
+    }
+
+    std::vector<float> toti(6 * np2);
+    int64_t nsel[6] = {0, 0, 0, 0, 0, 0};
+    int rc = slicer_plane_read(h, 0, &mapxytot[0], toti.data(), nsel);
+    if (rc != SLICER_OK) {
+        std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+        if (rc == SLICER_ERR_NEGATIVE_COORD)
+            std::cerr << "Aborting from Rank " << myid << std::endl;  // densitymaps.cpp:343
+        return 1;
+    }
+    for (int i = 0; i < 6; i++) {
+        std::copy(toti.begin() + i * np2, toti.begin() + (i + 1) * np2, &mapxytoti[i][0]);
+        ntotxyi[i] = g.true_counts ? (int)nsel[i] : 0;
+    }
+    if (myid == 0)
+        std::cout << " maps done! from Rank:" << myid << std::endl;
+    return 0;
+}

@@ -862,6 +862,37 @@ int slicer_plane_device_maps(slicer_handle h, int plane, float **d_tot, float **
     return SLICER_OK;
 }
 
+int slicer_get_stream(slicer_handle h, void **hip_stream)
+{
+    if (!h || !hip_stream)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    *hip_stream = (void *)h->stream;
+    return SLICER_OK;
+}
+
+int slicer_plane_info(slicer_handle h, int32_t *npix, int32_t *n_planes)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane)
+        return fail(h, SLICER_ERR_STATE, "no plane pass is open");
+    if (npix)
+        *npix = h->desc.npix;
+    if (n_planes)
+        *n_planes = h->desc.n_planes;
+    return SLICER_OK;
+}
+
+int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts)
+{
+    if (!h || !d_counts)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (plane < 0 || plane >= SLICER_MAX_PLANES)
+        return fail(h, SLICER_ERR_ARG, "plane %d out of range", plane);
+    *d_counts = (uint64_t *)(h->d_counts + (size_t)plane * 6);
+    return SLICER_OK;
+}
+
 int slicer_synchronize(slicer_handle h)
 {
     if (!h)

@@ -29,6 +29,18 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_rccl_library_exports_its_header():
+    """include/slicer_amd_rccl.h <-> libslicer_amd_rccl.so (load + symbols only; no communicator is created)."""
+    from slicer_amd import rccl
+    src = open(os.path.join(ROOT, "include", "slicer_amd_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(slicer_rccl_[a-z_0-9]+)\s*\(", src)))
+    lib = rccl.load()
+    assert names == sorted(rccl.SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n)
+
+
 def test_version_and_null_handle_errors():
     lib = _lib.load()
     assert lib.slicer_version() == 100

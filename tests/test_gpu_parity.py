@@ -386,3 +386,25 @@ def test_full_size_properties_256cubed_4096(S):
         mass = float(a[0].sum(dtype=np.float64)) / m
         assert 0.990 * nsel < mass <= nsel * (1 + 1e-6)
     assert 0.70 * n < tot_sel < 0.85 * n  # S8d geometry: ~77 % of the box lands in the four planes
+
+
+def test_rccl_plane_reduce_single_rank(S):
+    """slicer_amd_rccl.h on a one-rank communicator: the sum over ranks is the identity; exercises the
+    ncclReduce call sequence (maps + counters) on the handle's stream.  Multi-rank runs need >1 GPU."""
+    import ctypes as C
+    from slicer_amd import rccl
+    R = rccl.load()
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert R.slicer_rccl_comm_init_all(C.byref(comm), 1, dev) == 0, R.slicer_rccl_last_error()
+    files = [one_type_file(100000)]
+    ref_tot, ref_toti, nsel = run_oracle(files, 128, 0.25, 3.0, 4.0, ngp=True)
+    S.plane_begin(128, 0.25, [3.0], [4.0], mas=slicer_amd.MAS_NGP)
+    f = files[0]
+    S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    S.deposit_host(1, f["pos"])
+    S.file_end()
+    assert R.slicer_rccl_plane_reduce(S._h, comm, 0, 1) == 0, R.slicer_rccl_last_error()
+    tot, toti, cnt = S.plane_read(0)
+    assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32)) and np.array_equal(cnt, nsel)
+    R.slicer_rccl_comm_destroy(comm)
