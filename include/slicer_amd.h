@@ -85,7 +85,7 @@ typedef struct {
     double ld2[SLICER_MAX_PLANES];         /* Lens.ld2[isnap]                                    */
     int32_t nrepperp[SLICER_MAX_PLANES];   /* Lens.nrepperp[isnap] (data.h:114)                  */
     int32_t fixed_frac_bits;               /* SLICER_ACC_FIXED64: fractional bits, 0 = auto (40) */
-    int32_t reserved;
+    int32_t debug_flags;                   /* bit 0: always use libm (OCML) asin/atan2, no small-angle series */
 } slicer_plane_desc;
 
 /* Per sub-file state: the fields of Header (data.h:59-79) and of the plane's Random entry

@@ -13,7 +13,7 @@ class PlaneDesc(C.Structure):
     _fields_ = [("npix", C.c_int32), ("n_planes", C.c_int32), ("mas", C.c_int32), ("accum", C.c_int32),
                 ("algo", C.c_int32), ("hydro", C.c_int32), ("snopt", C.c_int32), ("want_type_maps", C.c_int32),
                 ("fov_rad", C.c_double), ("ld", C.c_double * MAX_PLANES), ("ld2", C.c_double * MAX_PLANES),
-                ("nrepperp", C.c_int32 * MAX_PLANES), ("fixed_frac_bits", C.c_int32), ("reserved", C.c_int32)]
+                ("nrepperp", C.c_int32 * MAX_PLANES), ("fixed_frac_bits", C.c_int32), ("debug_flags", C.c_int32)]
 
 
 class FileDesc(C.Structure):

@@ -121,7 +121,7 @@ class Slicer:
         self._chk(_L.slicer_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def plane_begin(self, npix, fov_rad, ld, ld2, nrepperp=None, mas=MAS_TSC, accum=ACC_F32, algo=ALGO_AUTO,
-                    hydro=False, snopt=0, want_type_maps=True, fixed_frac_bits=0):
+                    hydro=False, snopt=0, want_type_maps=True, fixed_frac_bits=0, debug_flags=0):
         ld = list(np.atleast_1d(ld))
         ld2 = list(np.atleast_1d(ld2))
         n = len(ld)
@@ -130,6 +130,7 @@ class Slicer:
         d.hydro, d.snopt, d.want_type_maps = int(bool(hydro)), int(snopt), int(bool(want_type_maps))
         d.fov_rad = float(fov_rad)
         d.fixed_frac_bits = int(fixed_frac_bits)
+        d.debug_flags = int(debug_flags)
         nrepperp = [0] * n if nrepperp is None else list(np.atleast_1d(nrepperp))
         for i in range(min(n, _lib.MAX_PLANES)):
             d.ld[i], d.ld2[i], d.nrepperp[i] = float(ld[i]), float(ld2[i]), int(nrepperp[i])

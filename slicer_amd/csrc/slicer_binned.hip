@@ -27,10 +27,10 @@ namespace slicer {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;     // scatter workgroup
+constexpr int kK1Block = 512;   // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
 constexpr int kPerThread = 4;
-constexpr int kRound = kBlock * kPerThread;  // particles per round of one K1 block
-constexpr int kQCap = kRound + kBlock;       // LDS queue capacity (one round + carried remainder)
+constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 workgroup
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
@@ -57,31 +57,81 @@ __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
 
 // ---------------------------------------------------------------------------------------------
 // K1: project + bin
+//
+// Every wave runs on its own: it streams 256 particles per round (4 per lane, three dwordx4 loads, the next
+// round's loads issued before the current round is processed), transforms them, and pushes the survivors of
+// the slab / FOV pre-test onto a wave-private LDS stack (positions from ballot + popcount, no atomics).
+// Whenever the stack holds >= 64 entries the wave pops 64 and runs the fp64 projection on a full wave.
+// There is no workgroup barrier in the loop; waves only share the histogram and the output cursor.
 // ---------------------------------------------------------------------------------------------
+constexpr int kWaves = kK1Block / 64;
+constexpr int kWaveQ = 64 * kPerThread + 64;  // stack capacity per wave: one round + a remainder < 64
+
+__device__ __forceinline__ void lds_fence()
+{
+    // LDS traffic of this wave is complete and the compiler may not move memory operations across
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool VEC, bool HAS_MASS>
+__device__ __forceinline__ void load_round(const float *__restrict__ pos, const float *__restrict__ mass, uint64_t i0,
+                                           int nvalid, float (&rx)[kPerThread], float (&ry)[kPerThread],
+                                           float (&rz)[kPerThread], float (&rm)[kPerThread])
+{
+    if (VEC && nvalid == kPerThread) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
+        const float4 a = p4[0], b = p4[1], c = p4[2];
+        rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
+        rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
+        rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
+        rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            if (k < nvalid) {
+                rx[k] = pos[3 * (i0 + k) + 0];
+                ry[k] = pos[3 * (i0 + k) + 1];
+                rz[k] = pos[3 * (i0 + k) + 2];
+            } else {
+                rx[k] = ry[k] = rz[k] = 0.f;
+            }
+        }
+    }
+    if (HAS_MASS) {
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++)
+            rm[k] = k < nvalid ? mass[i0 + k] : 0.f;
+    }
+}
+
 template <int MAS, bool POW2, bool HAS_MASS, bool VEC>
-__global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
+__global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
                                                         uint64_t n, PassParams P, BinGeom G,
-                                                        float2 *__restrict__ cxy, unsigned *__restrict__ cbin,
-                                                        float *__restrict__ cm, unsigned *__restrict__ hist,
+                                                        float2 *__restrict__ cxy, unsigned short *__restrict__ cbin,
+                                                        float *__restrict__ cm, unsigned *__restrict__ hist16,
                                                         unsigned *__restrict__ bcount, Targets T)
 {
     extern __shared__ unsigned smem[];
-    unsigned *s_hist = smem;  // [nbins]
-    float *qx = reinterpret_cast<float *>(smem + G.nbins);
-    float *qy = qx + kQCap;
-    float *qz = qy + kQCap;
-    int *qp = reinterpret_cast<int *>(qz + kQCap);
-    float *qm = reinterpret_cast<float *>(qp + kQCap);  // only with HAS_MASS
-    __shared__ unsigned s_q, s_out, s_cnt[kMaxPlanes];
+    // per-workgroup histogram, two 16-bit counters per word (a workgroup emits <= batch <= 65535 records)
+    unsigned *s_hist = smem;  // [hist_words]
+    const int hist_words = (G.nbins + 1) >> 1;
+    const int tid = threadIdx.x;
+    const unsigned lane = lane_id();
+    const int wave = tid >> 6;
+    // wave-private stack: x, y, z, plane (+ mass)
+    float *qx = reinterpret_cast<float *>(smem + hist_words) + (size_t)wave * kWaveQ * (HAS_MASS ? 5 : 4);
+    float *qy = qx + kWaveQ;
+    float *qz = qy + kWaveQ;
+    int *qp = reinterpret_cast<int *>(qz + kWaveQ);
+    float *qm = reinterpret_cast<float *>(qp + kWaveQ);  // only with HAS_MASS
+    __shared__ unsigned s_out, s_cnt[kMaxPlanes];
     __shared__ int s_neg;
 
-    const int tid = threadIdx.x;
-    for (int i = tid; i < G.nbins; i += kBlock)
+    for (int i = tid; i < hist_words; i += kK1Block)
         s_hist[i] = 0;
     if (tid < kMaxPlanes)
         s_cnt[tid] = 0;
     if (tid == 0) {
-        s_q = 0;
         s_out = 0;
         s_neg = 0;
     }
@@ -90,51 +140,44 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict_
     const uint64_t b0 = (uint64_t)blockIdx.x * G.batch;
     const uint64_t b1 = dmin<uint64_t>(n, b0 + G.batch);
     bool neg = false;
+    unsigned top = 0;  // entries on this wave's stack (wave-uniform)
 
-    for (uint64_t r0 = b0; r0 < b1; r0 += kRound) {
-        // ---- phase A: load 4 particles per thread, transform, slab select, enqueue survivors ----
-        const uint64_t i0 = r0 + (uint64_t)kPerThread * tid;
-        float rx[kPerThread], ry[kPerThread], rz[kPerThread], rm[kPerThread];
-        int nvalid = 0;
-        if (i0 < b1)
-            nvalid = (int)dmin<uint64_t>(kPerThread, b1 - i0);
-        if (VEC && nvalid == kPerThread) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
-            float4 a = p4[0], b = p4[1], c = p4[2];
-            rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
-            rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
-            rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
-            rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < kPerThread; k++) {
-                if (k < nvalid) {
-                    rx[k] = pos[3 * (i0 + k) + 0];
-                    ry[k] = pos[3 * (i0 + k) + 1];
-                    rz[k] = pos[3 * (i0 + k) + 2];
-                } else {
-                    rx[k] = ry[k] = rz[k] = 0.f;
-                }
-            }
-        }
-        if (HAS_MASS) {
-#pragma unroll
-            for (int k = 0; k < kPerThread; k++)
-                rm[k] = k < nvalid ? mass[i0 + k] : 0.f;
-        }
+    // round r of this wave covers particles [w0 + r*kRound, +256): lane l owns 4 consecutive ones
+    const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
+    float rx[kPerThread], ry[kPerThread], rz[kPerThread], rm[kPerThread];
+    float nx[kPerThread], ny[kPerThread], nz[kPerThread], nm[kPerThread];
+    uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
+    int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
+    load_round<VEC, HAS_MASS>(pos, mass, i0, nvalid, rx, ry, rz, rm);
+
+    for (uint64_t r0 = w0; r0 < b1; r0 += kRound) {
+        // prefetch the next round while this one is processed
+        const uint64_t i1 = i0 + kRound;
+        const bool more = r0 + kRound < b1;
+        const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
+        if (more)
+            load_round<VEC, HAS_MASS>(pos, mass, i1, nvalid1, nx, ny, nz, nm);
+
+        // ---- transform, slab select, conservative FOV pre-test, push ----
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
             float x, y, z;
-            transform(rx[k], ry[k], rz[k], P, x, y, z);
+            if (P.force_libm & 4) {
+                x = rx[k] * 1e-3f; y = ry[k] * 1e-3f; z = rz[k] * 1e-3f + 3.0f;
+            } else
+                transform(rx[k], ry[k], rz[k], P, x, y, z);
             const bool live = k < nvalid;
             neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
             int plane = -1;
-            for (int p = 0; p < P.n_planes; p++)
+#pragma unroll
+            for (int p = 0; p < kMaxPlanes; p++)  // constant indices: thresholds stay in SGPRs (unused planes: empty)
                 if (z >= P.zlo[p] && z < P.zhi[p])
                     plane = p;  // slabs are disjoint on this path (checked on the host)
-            const bool sel = live && plane >= 0;
-            unsigned slot = wave_reserve(sel, &s_q);
+            // entries that certainly fail the FOV cut never reach the fp64 projection
+            const bool sel = live && plane >= 0 && !surely_outside_fov(x, y, z, P);
+            const unsigned long long mask = __ballot(sel);
             if (sel) {
+                const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
                 qx[slot] = x;
                 qy[slot] = y;
                 qz[slot] = z;
@@ -142,22 +185,22 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict_
                 if (HAS_MASS)
                     qm[slot] = rm[k];
             }
+            top += (unsigned)__popcll(mask);
         }
-        __syncthreads();
+        lds_fence();
 
-        // ---- phase B: fp64 projection on dense groups of 256 queue entries ----
-        const unsigned q = s_q;
-        const bool last = r0 + kRound >= b1;
-        const unsigned nproc = last ? q : (q / kBlock) * kBlock;
-        for (unsigned g = 0; g < nproc; g += kBlock) {
-            const unsigned e = g + tid;
-            bool emit = false;
+        // ---- fp64 projection on full waves popped from the stack ----
+        while (top >= 64u || (!more && top > 0u)) {
+            const unsigned take = top >= 64u ? 64u : top;
+            const unsigned e = top - take + lane;
+            bool emit = false, valid = false;
             float xs = 0.f, ys = 0.f, m = 0.f;
             unsigned bin = 0;
-            if (e < nproc) {
-                const int plane = qp[e];
-                if (project(qx[e], qy[e], qz[e], 0, 0, P, xs, ys)) {
-                    atomicAdd(&s_cnt[plane], 1u);
+            int plane = 0;
+            if (lane < take) {
+                plane = qp[e];
+                if (!(P.force_libm & 2) && project(qx[e], qy[e], qz[e], 0, 0, P, xs, ys)) {
+                    valid = true;
                     int gx = grid_index<POW2>(xs, P);
                     int gy = grid_index<POW2>(ys, P);
                     const int nn = P.nn;
@@ -174,48 +217,42 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict_
                         m = qm[e];
                 }
             }
-            unsigned o = wave_reserve(emit, &s_out);
+            top -= take;
+            for (int p = 0; p < P.n_planes; p++) {  // one LDS add per wave and plane (not one per lane)
+                const unsigned c = (unsigned)__popcll(__ballot(valid && plane == p));
+                if (c && lane == 0)
+                    atomicAdd(&s_cnt[p], c);
+            }
+            const unsigned o = wave_reserve(emit, &s_out);
             if (emit) {
                 const uint64_t dst = b0 + o;
                 cxy[dst] = make_float2(xs, ys);
-                cbin[dst] = bin;
+                cbin[dst] = (unsigned short)bin;  // nbins <= 8192
                 if (HAS_MASS)
                     cm[dst] = m;
-                atomicAdd(&s_hist[bin], 1u);
+                atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
             }
         }
-        __syncthreads();
-        // ---- carry the remainder (< 256 entries) to the queue front ----
-        const unsigned rem = q - nproc;
-        float tx = 0, ty = 0, tz = 0, tm = 0;
-        int tp = 0;
-        if ((unsigned)tid < rem) {
-            tx = qx[nproc + tid];
-            ty = qy[nproc + tid];
-            tz = qz[nproc + tid];
-            tp = qp[nproc + tid];
+        lds_fence();
+
+        // rotate the prefetched round in
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+            rx[k] = nx[k];
+            ry[k] = ny[k];
+            rz[k] = nz[k];
             if (HAS_MASS)
-                tm = qm[nproc + tid];
+                rm[k] = nm[k];
         }
-        __syncthreads();
-        if ((unsigned)tid < rem) {
-            qx[tid] = tx;
-            qy[tid] = ty;
-            qz[tid] = tz;
-            qp[tid] = tp;
-            if (HAS_MASS)
-                qm[tid] = tm;
-        }
-        if (tid == 0)
-            s_q = rem;
-        __syncthreads();
+        i0 = i1;
+        nvalid = nvalid1;
     }
 
     if (neg)
         s_neg = 1;
     __syncthreads();
-    unsigned *row = hist + (size_t)blockIdx.x * G.nbins;
-    for (int i = tid; i < G.nbins; i += kBlock)
+    unsigned *row = hist16 + (size_t)blockIdx.x * hist_words;  // u16 [nbins] packed, row stride hist_words words
+    for (int i = tid; i < hist_words; i += kK1Block)
         row[i] = s_hist[i];
     if (tid == 0) {
         bcount[blockIdx.x] = s_out;
@@ -230,18 +267,20 @@ __global__ __launch_bounds__(kBlock) void k_project_bin(const float *__restrict_
 // K2a: per bin, exclusive prefix over workgroups (in place) + total.  One 256-thread workgroup owns
 // 16 bins x 16 segments of the workgroup axis: segment sums, a 16-way scan in LDS, then the prefix write.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan_blocks(unsigned *__restrict__ hist, unsigned *__restrict__ total,
+__global__ __launch_bounds__(256) void k_scan_blocks(const unsigned short *__restrict__ hist16,
+                                                     unsigned *__restrict__ prefix, unsigned *__restrict__ total,
                                                      int nblocks, int nbins)
 {
     __shared__ unsigned s_seg[16][17];
     const int bl = threadIdx.x & 15, seg = threadIdx.x >> 4;
     const int bin = blockIdx.x * 16 + bl;
+    const size_t stride16 = (size_t)((nbins + 1) >> 1) * 2;
     const int per = (nblocks + 15) / 16;
     const int lo = seg * per, hi = lo + per < nblocks ? lo + per : nblocks;
     unsigned sum = 0;
     if (bin < nbins)
         for (int b = lo; b < hi; b++)
-            sum += hist[(size_t)b * nbins + bin];
+            sum += hist16[(size_t)b * stride16 + bin];
     s_seg[seg][bl] = sum;
     __syncthreads();
     unsigned run = 0;
@@ -249,9 +288,8 @@ __global__ __launch_bounds__(256) void k_scan_blocks(unsigned *__restrict__ hist
         run += s_seg[k][bl];
     if (bin < nbins) {
         for (int b = lo; b < hi; b++) {
-            const size_t i = (size_t)b * nbins + bin;
-            unsigned v = hist[i];
-            hist[i] = run;
+            unsigned v = hist16[(size_t)b * stride16 + bin];
+            prefix[(size_t)b * nbins + bin] = run;
             run += v;
         }
         if (seg == 15)
@@ -291,7 +329,8 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__
 // K3: scatter records into their bin runs
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_MASS>
-__global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict__ cxy, const unsigned *__restrict__ cbin,
+__global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict__ cxy,
+                                                        const unsigned short *__restrict__ cbin,
                                                         const float *__restrict__ cm,
                                                         const unsigned *__restrict__ prefix,
                                                         const unsigned *__restrict__ base,
@@ -305,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_scatter(const float2 *__restrict
     // K1 workgroups lets its L2 merge the neighbouring short runs into whole lines before write-back.
     const int per_xcd = (nblocks + 7) / 8;
     const int lb = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (lb >= nblocks || (int)(blockIdx.x >> 3) >= per_xcd)
+    if (lb >= nblocks)
         return;
     const unsigned *row = prefix + (size_t)lb * G.nbins;
     for (int i = tid; i < G.nbins; i += kBlock)
@@ -485,7 +524,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 // ---------------------------------------------------------------------------------------------
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
 {
-    return sizeof(unsigned) * (size_t)G.nbins + (size_t)kQCap * (has_mass ? 20 : 16);
+    return sizeof(unsigned) * (size_t)((G.nbins + 1) >> 1) + (size_t)kWaves * kWaveQ * (has_mass ? 20 : 16);
 }
 
 template <int MAS, bool POW2, bool HAS_MASS>
@@ -495,11 +534,11 @@ static hipError_t launch_k1(bool vec, const float *pos, const float *mass, uint6
     const int nb = (int)((n + G.batch - 1) / G.batch);
     const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
     if (vec)
-        k_project_bin<MAS, POW2, HAS_MASS, true><<<nb, kBlock, lds, s>>>(pos, mass, n, P, G, W.cxy, W.cbin, W.cm,
-                                                                         W.hist, W.bcount, T);
+        k_project_bin<MAS, POW2, HAS_MASS, true><<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm,
+                                                                         W.hist16, W.bcount, T);
     else
-        k_project_bin<MAS, POW2, HAS_MASS, false><<<nb, kBlock, lds, s>>>(pos, mass, n, P, G, W.cxy, W.cbin, W.cm,
-                                                                          W.hist, W.bcount, T);
+        k_project_bin<MAS, POW2, HAS_MASS, false><<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm,
+                                                                          W.hist16, W.bcount, T);
     return hipGetLastError();
 }
 
@@ -523,7 +562,8 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
 
 hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
 {
-    k_scan_blocks<<<(G.nbins + 15) / 16, 256, 0, s>>>(W.hist, W.total, nblocks, G.nbins);
+    k_scan_blocks<<<(G.nbins + 15) / 16, 256, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
+                                                         nblocks, G.nbins);
     k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins);
     return hipGetLastError();
 }
@@ -534,10 +574,10 @@ hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, cons
     const int grid = 8 * ((nblocks + 7) / 8);
     static const int dbg = getenv("SLICER_DBG_SCATTER") ? atoi(getenv("SLICER_DBG_SCATTER")) : 0;
     if (has_mass)
-        k_bin_scatter<true><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<true><<<grid, kBlock, lds, s>>>(W.cxy, reinterpret_cast<const unsigned short *>(W.cbin), W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                       W.sm, dbg);
     else
-        k_bin_scatter<false><<<grid, kBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<false><<<grid, kBlock, lds, s>>>(W.cxy, reinterpret_cast<const unsigned short *>(W.cbin), W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                        W.sm, dbg);
     return hipGetLastError();
 }

@@ -74,7 +74,7 @@ struct slicer_handle_s {
     uint64_t stage_cap = 0;  // particles
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
-    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_total, w_bcount;
+    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount;
     DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
     // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
     PendingList pend{};
@@ -236,8 +236,19 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
         P.zhi[p] = ceil_to_f32(maxDist);
         P.nrep[p] = d.nrepperp[p];
     }
+    for (int p = d.n_planes; p < kMaxPlanes; p++) {  // unused slots select nothing (kernels may unroll over all 8)
+        P.zlo[p] = INFINITY;
+        P.zhi[p] = -INFINITY;
+    }
     P.fov = d.fov_rad;
+    P.inv_fov = 1.0 / d.fov_rad;
     P.lim = d.fov_rad * (1. + 2. / d.npix) * 0.5;  // densitymaps.cpp:383
+    if (P.lim < 1.5) {
+        P.tan_lim_hi = (float)(std::tan(P.lim) * (1.0 + 1e-5));
+        P.sin2_lim_hi = (float)(std::sin(P.lim) * std::sin(P.lim) * (1.0 + 1e-5));
+    }
+    static const int force_libm = getenv("SLICER_FORCE_LIBM") ? atoi(getenv("SLICER_FORCE_LIBM")) : 0;
+    P.force_libm = force_libm | (d.debug_flags & 1);
     P.nn = d.npix;
     P.pow2 = is_pow2(d.npix) ? 1 : 0;
     P.dl = 1. / double(d.npix);  // utilities.cpp:50
@@ -395,7 +406,7 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, B
     const uint64_t nbmax = (cap + 4096 - 1) / 4096;
     int rc;
     if ((rc = ensure(h, h->w_cxy, cap * 8)) || (rc = ensure(h, h->w_cbin, cap * 4)) ||
-        (rc = ensure(h, h->w_hist, nbmax * kMaxBins * 4)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
+        (rc = ensure(h, h->w_hist, nbmax * kMaxBins * 4)) || (rc = ensure(h, h->w_hist16, nbmax * kMaxBins * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
         (rc = ensure(h, h->w_bcount, nbmax * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
         (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
@@ -407,6 +418,7 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, B
     W.sxy = (float2 *)h->w_sxy[slot].p;
     W.sm = (float *)h->w_sm[slot].p;
     W.hist = (unsigned *)h->w_hist.p;
+    W.hist16 = (unsigned *)h->w_hist16.p;
     W.total = (unsigned *)h->w_total.p;
     W.base = (unsigned *)h->w_base[slot].p;
     W.bcount = (unsigned *)h->w_bcount.p;
@@ -600,7 +612,7 @@ int slicer_destroy(slicer_handle h)
             release(pl.acc[t]);
         }
     }
-    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_total, &h->w_bcount})
+    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount})
         release(*b);
     for (int i = 0; i < kMaxPending; i++) {
         release(h->w_sxy[i]);

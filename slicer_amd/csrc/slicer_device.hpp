@@ -32,7 +32,10 @@ struct PassParams {
     int nrep[kMaxPlanes];
     // --- projection (densitymaps.cpp:382-386) ---
     double fov;
-    double lim;  // fov * (1. + 2. / npix) * 0.5
+    double inv_fov;  // RN(1/fov): fast path of to_map_coord()
+    double lim;      // fov * (1. + 2. / npix) * 0.5
+    float tan_lim_hi, sin2_lim_hi;  // tan(lim) and sin^2(lim), inflated by 1e-5: surely_outside_fov()
+    int force_libm;  // debug: always use OCML asin/atan2
     // --- grid (utilities.cpp:50,69-70) ---
     int nn;
     int pow2;        // nn is a power of two: x / dl == x * nn exactly
@@ -52,16 +55,25 @@ struct PassParams {
 // from the correctly rounded quotient) gives the same f32 unless it sits within a few ulp of an
 // f32 rounding tie (bit 28 of the f64 mantissa set, bits 27..0 clear) or in the f32 subnormal
 // range; those rare cases (p ~ 2^-24) take the exact division.
-__device__ __forceinline__ float div_by_box(float r, const PassParams &P)
+__device__ __forceinline__ bool box_quotient_risky(double q)
 {
-    double q = (double)r * P.inv_box;
-    unsigned long long b = (unsigned long long)__double_as_longlong(q);
-    unsigned lo = (unsigned)b & 0x1FFFFFFFu;
-    unsigned ex = (unsigned)(b >> 52) & 0x7FFu;
-    bool risky = ((lo - 0x0FFFFFF0u) <= 0x20u) | (ex < 1023u - 125u);
-    if (risky)
-        q = (double)r / P.box;
-    return (float)q;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(q);
+    const unsigned lo = (unsigned)b & 0x1FFFFFFFu;
+    const unsigned ex = (unsigned)(b >> 52) & 0x7FFu;
+    return ((lo - 0x0FFFFFF0u) <= 0x20u) | (ex < 1023u - 125u);
+}
+
+// exact quotients for the rare lanes that need them; out of line so that the three IEEE divisions are
+// really branched around (inlined, the compiler if-converts them into every particle's instruction stream)
+__device__ __attribute__((noinline)) void div_by_box_exact(float rx, float ry, float rz, double box, double &qx,
+                                                           double &qy, double &qz)
+{
+    if (box_quotient_risky(qx))
+        qx = (double)rx / box;
+    if (box_quotient_risky(qy))
+        qy = (double)ry / box;
+    if (box_quotient_risky(qz))
+        qz = (double)rz / box;
 }
 
 // gadget2io.cpp:209-220 / 258-269.  The reference evaluates "v - 1." and "1. + v" in double and
@@ -80,10 +92,13 @@ __device__ __forceinline__ float wrap01(float v)
 __device__ __forceinline__ void transform(float rx, float ry, float rz, const PassParams &P, float &x, float &y,
                                           float &z)
 {
+    double qx = (double)rx * P.inv_box, qy = (double)ry * P.inv_box, qz = (double)rz * P.inv_box;
+    if (__ballot(box_quotient_risky(qx) | box_quotient_risky(qy) | box_quotient_risky(qz)) != 0ull)
+        div_by_box_exact(rx, ry, rz, P.box, qx, qy, qz);  // wave-uniform branch, p ~ 1e-5 per wave
     float b[3];
-    b[0] = wrap01(P.sgn[0] * div_by_box(rx, P));  // sign flip is exact in any precision
-    b[1] = wrap01(P.sgn[1] * div_by_box(ry, P));
-    b[2] = wrap01(P.sgn[2] * div_by_box(rz, P));
+    b[0] = wrap01(P.sgn[0] * (float)qx);  // sign flip is exact in any precision
+    b[1] = wrap01(P.sgn[1] * (float)qy);
+    b[2] = wrap01(P.sgn[2] * (float)qz);
     // perm is wave-uniform: three selects each
     float v0 = P.perm[0] == 0 ? b[0] : (P.perm[0] == 1 ? b[1] : b[2]);
     float v1 = P.perm[1] == 0 ? b[0] : (P.perm[1] == 1 ? b[1] : b[2]);
@@ -94,10 +109,84 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
     z = z + P.rcase;
 }
 
+// ---- small-angle asin / atan ----------------------------------------------------------------
+// For |x| <= 0.3125 (fields of view up to ~36 deg) asin and atan are evaluated by their Taylor series
+// in the form x + x*z*P(z), z = x^2, 15 terms: truncation < 0.03 ulp, and because the correction term is
+// < 3.5 % of the result the Horner rounding stays below 0.02 ulp, so the value is within ~0.52 ulp (asin)
+// and ~1.02 ulp (atan, including the rounding of the quotient y/z) of the exact one -- the accuracy class
+// of glibc's and OCML's routines, which are used outside that range.  A1..A15 = (2k)!/(4^k k!^2 (2k+1)).
+__device__ __forceinline__ double asin_small(double x)
+{
+    const double z = x * x;
+    double p = 0x1.31683bdef7bdfp-8;
+    p = fma(p, z, 0x1.51ba308d3dcb1p-8);
+    p = fma(p, z, 0x1.782dda12f684cp-8);
+    p = fma(p, z, 0x1.a6863d70a3d71p-8);
+    p = fma(p, z, 0x1.df3bd37a6f4dfp-8);
+    p = fma(p, z, 0x1.12ef3cf3cf3cfp-7);
+    p = fma(p, z, 0x1.3fde50d79435ep-7);
+    p = fma(p, z, 0x1.7a87878787878p-7);
+    p = fma(p, z, 0x1.c99999999999ap-7);
+    p = fma(p, z, 0x1.1c4ec4ec4ec4fp-6);
+    p = fma(p, z, 0x1.6e8ba2e8ba2e9p-6);
+    p = fma(p, z, 0x1.f1c71c71c71c7p-6);
+    p = fma(p, z, 0x1.6db6db6db6db7p-5);
+    p = fma(p, z, 0x1.3333333333333p-4);
+    p = fma(p, z, 0x1.5555555555555p-3);
+    return fma(x * z, p, x);
+}
+
+__device__ __forceinline__ double atan_small(double t)
+{
+    const double z = t * t;
+    double p = -0x1.0842108421084p-5;
+    p = fma(p, z, 0x1.1a7b9611a7b96p-5);
+    p = fma(p, z, -0x1.2f684bda12f68p-5);
+    p = fma(p, z, 0x1.47ae147ae147bp-5);
+    p = fma(p, z, -0x1.642c8590b2164p-5);
+    p = fma(p, z, 0x1.8618618618618p-5);
+    p = fma(p, z, -0x1.af286bca1af28p-5);
+    p = fma(p, z, 0x1.e1e1e1e1e1e1ep-5);
+    p = fma(p, z, -0x1.1111111111111p-4);
+    p = fma(p, z, 0x1.3b13b13b13b14p-4);
+    p = fma(p, z, -0x1.745d1745d1746p-4);
+    p = fma(p, z, 0x1.c71c71c71c71cp-4);
+    p = fma(p, z, -0x1.2492492492492p-3);
+    p = fma(p, z, 0x1.999999999999ap-3);
+    p = fma(p, z, -0x1.5555555555555p-2);
+    return fma(t * z, p, t);
+}
+
+// (float)(ang / fov + 0.5)      densitymaps.cpp:385-386
+// RN64(ang * RN64(1/fov)) + 0.5 is within 2^-51 (absolute, |ang/fov| < 1) of the reference's f64 value, so
+// its rounding to f32 is the reference's unless it sits that close to an f32 tie; those cases, and values
+// that are not in (2^-27, 1], take the exact division.
+__device__ __forceinline__ float to_map_coord(double ang, const PassParams &P)
+{
+    double s = ang * P.inv_fov + 0.5;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    const unsigned ex = (unsigned)(b >> 52) & 0xFFFu;  // sign + exponent: negative values fail the range test
+    const unsigned lo = (unsigned)b & 0x1FFFFFFFu;
+    const unsigned dist = lo > 0x10000000u ? lo - 0x10000000u : 0x10000000u - lo;
+    const bool in_range = ex >= 1023u - 27u && ex <= 1023u;
+    const unsigned sh = 1025u - ex;  // 2^(2-e) ulps of s  >=  2^-50 absolute
+    if (!in_range || dist <= (1u << (sh > 28u ? 28u : sh)))
+        s = ang / P.fov + 0.5;
+    return (float)s;
+}
+
 // A3: getPolar(radec) + FOV test + map coordinates.   densitymaps.cpp:382-386, utilities.cpp:23-25
-// sqrt and the two divisions are IEEE correctly rounded; asin/atan2 are OCML's (<= 1-2 ulp, like
-// glibc's): after the rounding to f32 the outputs agree with the CPU except when the f64 value lies
-// within ~2 ulp(f64) of an f32 tie (p ~ 1e-8 per coordinate; see DESIGN.md "libm").
+// sqrt and the divisions are IEEE correctly rounded; asin/atan2 are the small-angle series above or OCML's
+// (<= 1-2 ulp, like glibc's): after the rounding to f32 the outputs agree with the CPU except when the f64
+// value lies within ~2 ulp(f64) of an f32 tie (p ~ 1e-8 per coordinate; see DESIGN.md "Arithmetic fidelity").
+// out-of-range arguments (wide fields of view, z <= 0, NaN): OCML's asin / atan2.  Kept out of line so that
+// the register budget of the callers is set by the series path.
+__device__ __attribute__((noinline)) void polar_libm(double q, double Y, double Z, double &dec, double &ra)
+{
+    dec = asin(q);
+    ra = atan2(Y, Z);
+}
+
 __device__ __forceinline__ bool project(float x, float y, float z, int ni, int nj, const PassParams &P, float &xs,
                                         float &ys)
 {
@@ -107,13 +196,31 @@ __device__ __forceinline__ bool project(float x, float y, float z, int ni, int n
     double Y = (double)yf - 0.5;
     double Z = (double)z;
     double d = sqrt(X * X + Y * Y + Z * Z);
-    double dec = asin(X / d);
-    double ra = atan2(Y, Z);
+    double q = X / d;
+    double dec, ra;
+    if (fabs(q) <= 0.3125 && Z > 0.0 && fabs(Y) <= 0.3125 * Z && !(P.force_libm & 1)) {
+        dec = asin_small(q);
+        ra = atan_small(Y / Z);
+    } else {
+        polar_libm(q, Y, Z, dec, ra);
+    }
     if (!(fabs(ra) <= P.lim && fabs(dec) <= P.lim))
         return false;  // NaN (d == 0) is rejected, as in the reference
-    xs = (float)(dec / P.fov + 0.5);
-    ys = (float)(ra / P.fov + 0.5);
+    xs = to_map_coord(dec, P);
+    ys = to_map_coord(ra, P);
     return true;
+}
+
+// Conservative f32 pre-test of the FOV cut for the unreplicated case: true only if the entry certainly
+// fails |ra| <= lim or |dec| <= lim (margins 1e-5 relative + 1e-6 absolute dwarf every f32 rounding here),
+// so skipping it cannot change the result.  |ra| > lim <=> |Y| > Z tan(lim);  |dec| > lim <=> X^2 > sin^2(lim) d^2.
+__device__ __forceinline__ bool surely_outside_fov(float x, float y, float z, const PassParams &P)
+{
+    const float X = x - 0.5f, Y = y - 0.5f;
+    const float s = X * X + Y * Y + z * z;
+    const bool out_ra = fabsf(Y) > z * P.tan_lim_hi + 1e-6f;
+    const bool out_dec = X * X > P.sin2_lim_hi * s + 1e-6f;
+    return (out_ra | out_dec) & (z > 0.0f) & (P.lim < 1.5);
 }
 
 // floor(x / dl) as int.   utilities.cpp:69-70

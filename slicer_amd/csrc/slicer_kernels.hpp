@@ -68,11 +68,12 @@ struct BinGeom {
 
 struct BinWorkspace {
     float2 *cxy;       // [max_chunk] compact (xs, ys), workgroup b owns [b*batch, b*batch + bcount[b])
-    unsigned *cbin;    // [max_chunk] bin of each compact record
+    unsigned *cbin;    // [max_chunk] u16 bin of each compact record (nbins <= 8192)
     float *cm;         // [max_chunk] per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
     float *sm;         // [max_chunk] or nullptr
-    unsigned *hist;    // [nblocks][nbins] per-workgroup histogram, scanned in place
+    unsigned *hist16;  // [nblocks][ceil(nbins/2)] per-workgroup histogram, two u16 counters per word
+    unsigned *hist;    // [nblocks][nbins] exclusive prefix over workgroups (write cursors)
     unsigned *total;   // [nbins]
     unsigned *base;    // [nbins + 1] start of every bin's run in sxy
     unsigned *bcount;  // [nblocks]

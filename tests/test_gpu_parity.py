@@ -152,6 +152,35 @@ def test_project_bits_large_sample(S):
     assert bad == 0, f"{bad} of {2 * cnt} coordinates differ in the last bit"
 
 
+def test_small_angle_series_equals_libm_path(S):
+    """The 15-term asin/atan series (|x| <= 0.3125) against OCML's asin/atan2 on the device: the f32 map
+    coordinates of 2^23 particles must agree bit for bit (both are <= ~1 ulp(f64) routines)."""
+    n = 1 << 23
+    d = S.malloc(12 * n)
+    S.synth_positions(d, 0, n, BOX, seed=77)
+    outs = []
+    for flags in (0, 1):
+        S.plane_begin(4096, 0.5, [3.0], [4.0], debug_flags=flags)
+        S.file_begin([0, n, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        cnt, xs, ys, pl, src = S.debug_project(1, d, n, n)
+        S.file_end()
+        o = np.argsort(src)
+        outs.append((cnt, src[o], xs[o].view(np.uint32), ys[o].view(np.uint32)))
+    S.free(d)
+    assert outs[0][0] == outs[1][0] > n // 2
+    assert np.array_equal(outs[0][1], outs[1][1])
+    bad = int((outs[0][2] != outs[1][2]).sum() + (outs[0][3] != outs[1][3]).sum())
+    assert bad <= 1, f"{bad} of {2 * outs[0][0]} coordinates differ between the series and libm"
+
+
+def test_large_fov_uses_libm_path(S):
+    """fov = 1.2 rad: arguments leave the series' range; parity with the oracle must hold there too."""
+    files = [one_type_file(200000)]
+    ref_tot, _, nsel = run_oracle(files, 256, 1.2, 0.2, 0.9, ngp=True, rnd=dict(RND, rcase=0.0))
+    (tot, _, cnt), = run_gpu(S, files, 256, 1.2, 0.2, 0.9, ngp=True, rnd=dict(RND, rcase=0.0))
+    assert np.array_equal(cnt, nsel) and np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+
+
 @pytest.mark.parametrize("npix", [64, 256, 100, 1000])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
 def test_ngp_bit_exact(S, npix, algo):
