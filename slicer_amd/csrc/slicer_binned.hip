@@ -118,12 +118,10 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
     const int tid = threadIdx.x;
     const unsigned lane = lane_id();
     const int wave = tid >> 6;
-    // wave-private stack: x, y, z, plane (+ mass)
-    float *qx = reinterpret_cast<float *>(smem + hist_words) + (size_t)wave * kWaveQ * (HAS_MASS ? 5 : 4);
-    float *qy = qx + kWaveQ;
-    float *qz = qy + kWaveQ;
-    int *qp = reinterpret_cast<int *>(qz + kWaveQ);
-    float *qm = reinterpret_cast<float *>(qp + kWaveQ);  // only with HAS_MASS
+    // wave-private stack of float4 {x, y, z, plane bits} (+ a parallel mass array): one ds_write_b128 per push
+    float4 *q4 = reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) + (size_t)wave * kWaveQ;
+    float *qm = reinterpret_cast<float *>(reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) +
+                                          (size_t)kWaves * kWaveQ) + (size_t)wave * kWaveQ;  // only with HAS_MASS
     __shared__ unsigned s_out, s_cnt[kMaxPlanes];
     __shared__ int s_neg;
 
@@ -168,20 +166,26 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
                 transform(rx[k], ry[k], rz[k], P, x, y, z);
             const bool live = k < nvalid;
             neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
+            // slabs are disjoint on this path (checked on the host); constant indices keep the thresholds in
+            // SGPRs, unused slots are empty intervals; the common <= 4-plane case tests half of them
             int plane = -1;
+            if (P.n_planes <= 4) {
 #pragma unroll
-            for (int p = 0; p < kMaxPlanes; p++)  // constant indices: thresholds stay in SGPRs (unused planes: empty)
-                if (z >= P.zlo[p] && z < P.zhi[p])
-                    plane = p;  // slabs are disjoint on this path (checked on the host)
+                for (int p = 0; p < 4; p++)
+                    if (z >= P.zlo[p] && z < P.zhi[p])
+                        plane = p;
+            } else {
+#pragma unroll
+                for (int p = 0; p < kMaxPlanes; p++)
+                    if (z >= P.zlo[p] && z < P.zhi[p])
+                        plane = p;
+            }
             // entries that certainly fail the FOV cut never reach the fp64 projection
             const bool sel = live && plane >= 0 && !surely_outside_fov(x, y, z, P);
             const unsigned long long mask = __ballot(sel);
             if (sel) {
                 const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                qx[slot] = x;
-                qy[slot] = y;
-                qz[slot] = z;
-                qp[slot] = plane;
+                q4[slot] = make_float4(x, y, z, __int_as_float(plane));
                 if (HAS_MASS)
                     qm[slot] = rm[k];
             }
@@ -198,8 +202,9 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
             unsigned bin = 0;
             int plane = 0;
             if (lane < take) {
-                plane = qp[e];
-                if (!(P.force_libm & 2) && project(qx[e], qy[e], qz[e], 0, 0, P, xs, ys)) {
+                const float4 ent = q4[e];
+                plane = __float_as_int(ent.w);
+                if (!(P.force_libm & 2) && project(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
                     valid = true;
                     int gx = grid_index<POW2>(xs, P);
                     int gy = grid_index<POW2>(ys, P);
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 // ---------------------------------------------------------------------------------------------
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
 {
-    return sizeof(unsigned) * (size_t)((G.nbins + 1) >> 1) + (size_t)kWaves * kWaveQ * (has_mass ? 20 : 16);
+    return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * (has_mass ? 20 : 16);
 }
 
 template <int MAS, bool POW2, bool HAS_MASS>

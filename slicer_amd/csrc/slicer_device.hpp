@@ -57,10 +57,10 @@ struct PassParams {
 // range; those rare cases (p ~ 2^-24) take the exact division.
 __device__ __forceinline__ bool box_quotient_risky(double q)
 {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(q);
-    const unsigned lo = (unsigned)b & 0x1FFFFFFFu;
-    const unsigned ex = (unsigned)(b >> 52) & 0x7FFu;
-    return ((lo - 0x0FFFFFF0u) <= 0x20u) | (ex < 1023u - 125u);
+    // near an f32 rounding tie (bits 28..0 of the mantissa within 2^4 of 0x10000000) or so small that the f32
+    // result is subnormal or zero-ish (|q| < 2^-100, tested on the rounded value): 4 VALU ops
+    const unsigned lo = (unsigned)__double_as_longlong(q) & 0x1FFFFFFFu;
+    return ((lo - 0x0FFFFFF0u) <= 0x20u) | (fabsf((float)q) < 0x1p-100f);
 }
 
 // exact quotients for the rare lanes that need them; out of line so that the three IEEE divisions are
