@@ -400,17 +400,18 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     return true;
 }
 
-int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, BinWorkspace &W)
+int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, const BinGeom &G, BinWorkspace &W)
 {
-    const uint64_t cap = h->max_chunk;
-    const uint64_t nbmax = (cap + 4096 - 1) / 4096;
+    const uint64_t nb = (n + G.batch - 1) / G.batch;
+    const uint64_t region = (uint64_t)h->desc.n_planes * nb * G.batch;  // compact records: [plane][workgroup][batch]
     int rc;
-    if ((rc = ensure(h, h->w_cxy, cap * 8)) || (rc = ensure(h, h->w_cbin, cap * 4)) ||
-        (rc = ensure(h, h->w_hist, nbmax * kMaxBins * 4)) || (rc = ensure(h, h->w_hist16, nbmax * kMaxBins * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
-        (rc = ensure(h, h->w_bcount, nbmax * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
+    if ((rc = ensure(h, h->w_cxy, region * 8)) || (rc = ensure(h, h->w_cbin, region * 2)) ||
+        (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
+        (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
+        (rc = ensure(h, h->w_bcount, nb * SLICER_MAX_PLANES * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
         (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
-    if (has_mass && ((rc = ensure(h, h->w_cm, cap * 4)) || (rc = ensure(h, h->w_sm[slot], n * 4))))
+    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], n * 4))))
         return rc;
     W.cxy = (float2 *)h->w_cxy.p;
     W.cbin = (unsigned *)h->w_cbin.p;
@@ -449,7 +450,8 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     fill_targets(h, type, has_mass, T);
     LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
     BinGeom G;
-    bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G);
+    bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G) &&
+                  scatter_lds_bytes(G, has_mass) <= 160 * 1024 - 256;
     if (binned && d.algo == SLICER_ALGO_AUTO && n < 65536)
         binned = false;  // several launches are not worth it for a tiny chunk
     if (!binned) {
@@ -464,7 +466,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         return rc;
     const int slot = h->pend.n;
     BinWorkspace W;
-    if ((rc = ensure_bin_workspace(h, has_mass, slot, n, W)))
+    if ((rc = ensure_bin_workspace(h, has_mass, slot, n, G, W)))
         return rc;
     const int nblocks = (int)((n + G.batch - 1) / G.batch);
     {
@@ -477,7 +479,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, G, W, h->stream));
+        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, d.n_planes, G, W, h->stream));
     }
     if (slot == 0) {
         h->pend_key = key;

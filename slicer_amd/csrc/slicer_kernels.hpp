@@ -67,7 +67,7 @@ struct BinGeom {
 };
 
 struct BinWorkspace {
-    float2 *cxy;       // [max_chunk] compact (xs, ys), workgroup b owns [b*batch, b*batch + bcount[b])
+    float2 *cxy;       // [n_planes][nblocks][batch] compact (xs, ys) of (plane, K1 workgroup), bcount[plane][b] valid
     unsigned *cbin;    // [max_chunk] u16 bin of each compact record (nbins <= 8192)
     float *cm;         // [max_chunk] per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
@@ -76,16 +76,18 @@ struct BinWorkspace {
     unsigned *hist;    // [nblocks][nbins] exclusive prefix over workgroups (write cursors)
     unsigned *total;   // [nbins]
     unsigned *base;    // [nbins + 1] start of every bin's run in sxy
-    unsigned *bcount;  // [nblocks]
+    unsigned *bcount;  // [n_planes][nblocks]
 };
 
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
 size_t tile_lds_bytes(const BinGeom &G, int acc);
+size_t scatter_lds_bytes(const BinGeom &G, bool has_mass);
 hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
                               const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
                               hipStream_t s);
 hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
+                              hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
 constexpr int kMaxPending = 8;
