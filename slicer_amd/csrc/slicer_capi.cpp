@@ -225,8 +225,11 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
     // gadget2io.cpp:222-252: face -> (x,y,z) = wrapped[perm]
     static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
     int fi = (f.face >= 1 && f.face <= 6) ? f.face - 1 : 0;  // any other value leaves case 1 (switch falls through)
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 3; a++) {
         P.perm[a] = perms[fi][a];
+        for (int c = 0; c < 3; c++)
+            P.pm[a][c] = perms[fi][a] == c ? 0xFFFFFFFFu : 0u;
+    }
     P.rcase = f.rcase;
     P.n_planes = d.n_planes;
     for (int p = 0; p < d.n_planes; p++) {

@@ -24,6 +24,7 @@ struct PassParams {
     double c0[3];    // Random.x0,y0,z0
     float sgn[3];    // Random.sgnX,Y,Z as +-1.0f
     int perm[3];     // face permutation: out[a] = wrapped[perm[a]]
+    unsigned pm[3][3];  // the same as bit masks: pm[a][c] = all ones iff perm[a] == c
     float rcase;
     // --- planes (densitymaps.cpp:346-347,374) ---
     int n_planes;
@@ -63,17 +64,12 @@ __device__ __forceinline__ bool box_quotient_risky(double q)
     return ((lo - 0x0FFFFFF0u) <= 0x20u) | (fabsf((float)q) < 0x1p-100f);
 }
 
-// exact quotients for the rare lanes that need them; out of line so that the three IEEE divisions are
-// really branched around (inlined, the compiler if-converts them into every particle's instruction stream)
-__device__ __attribute__((noinline)) void div_by_box_exact(float rx, float ry, float rz, double box, double &qx,
-                                                           double &qy, double &qz)
+// exact quotient for the rare lanes that need it; out of line (and by value: no address-taken locals) so
+// that the IEEE division is really branched around -- inlined, the compiler if-converts it into every
+// particle's instruction stream
+__device__ __attribute__((noinline)) double div_by_box_exact(float r, double box, double q)
 {
-    if (box_quotient_risky(qx))
-        qx = (double)rx / box;
-    if (box_quotient_risky(qy))
-        qy = (double)ry / box;
-    if (box_quotient_risky(qz))
-        qz = (double)rz / box;
+    return box_quotient_risky(q) ? (double)r / box : q;
 }
 
 // gadget2io.cpp:209-220 / 258-269.  The reference evaluates "v - 1." and "1. + v" in double and
@@ -93,16 +89,19 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
                                           float &z)
 {
     double qx = (double)rx * P.inv_box, qy = (double)ry * P.inv_box, qz = (double)rz * P.inv_box;
-    if (__ballot(box_quotient_risky(qx) | box_quotient_risky(qy) | box_quotient_risky(qz)) != 0ull)
-        div_by_box_exact(rx, ry, rz, P.box, qx, qy, qz);  // wave-uniform branch, p ~ 1e-5 per wave
-    float b[3];
-    b[0] = wrap01(P.sgn[0] * (float)qx);  // sign flip is exact in any precision
-    b[1] = wrap01(P.sgn[1] * (float)qy);
-    b[2] = wrap01(P.sgn[2] * (float)qz);
-    // perm is wave-uniform: three selects each
-    float v0 = P.perm[0] == 0 ? b[0] : (P.perm[0] == 1 ? b[1] : b[2]);
-    float v1 = P.perm[1] == 0 ? b[0] : (P.perm[1] == 1 ? b[1] : b[2]);
-    float v2 = P.perm[2] == 0 ? b[0] : (P.perm[2] == 1 ? b[1] : b[2]);
+    if (__ballot(box_quotient_risky(qx) | box_quotient_risky(qy) | box_quotient_risky(qz)) != 0ull) {
+        qx = div_by_box_exact(rx, P.box, qx);  // wave-uniform branch, p ~ 1e-5 per wave
+        qy = div_by_box_exact(ry, P.box, qy);
+        qz = div_by_box_exact(rz, P.box, qz);
+    }
+    unsigned b[3];
+    b[0] = __float_as_uint(wrap01(P.sgn[0] * (float)qx));  // sign flip is exact in any precision
+    b[1] = __float_as_uint(wrap01(P.sgn[1] * (float)qy));
+    b[2] = __float_as_uint(wrap01(P.sgn[2] * (float)qz));
+    // face permutation as bit selects with scalar masks (v_bfi_b32): out[a] = b[perm[a]]
+    const float v0 = __uint_as_float((b[0] & P.pm[0][0]) | (b[1] & P.pm[0][1]) | (b[2] & P.pm[0][2]));
+    const float v1 = __uint_as_float((b[0] & P.pm[1][0]) | (b[1] & P.pm[1][1]) | (b[2] & P.pm[1][2]));
+    const float v2 = __uint_as_float((b[0] & P.pm[2][0]) | (b[1] & P.pm[2][1]) | (b[2] & P.pm[2][2]));
     x = wrap01((float)((double)v0 - P.c0[0]));
     y = wrap01((float)((double)v1 - P.c0[1]));
     z = wrap01((float)((double)v2 - P.c0[2]));
@@ -181,10 +180,15 @@ __device__ __forceinline__ float to_map_coord(double ang, const PassParams &P)
 // value lies within ~2 ulp(f64) of an f32 tie (p ~ 1e-8 per coordinate; see DESIGN.md "Arithmetic fidelity").
 // out-of-range arguments (wide fields of view, z <= 0, NaN): OCML's asin / atan2.  Kept out of line so that
 // the register budget of the callers is set by the series path.
-__device__ __attribute__((noinline)) void polar_libm(double q, double Y, double Z, double &dec, double &ra)
+struct Polar {
+    double dec, ra;
+};
+__device__ __attribute__((noinline)) Polar polar_libm(double q, double Y, double Z)
 {
-    dec = asin(q);
-    ra = atan2(Y, Z);
+    Polar r;
+    r.dec = asin(q);
+    r.ra = atan2(Y, Z);
+    return r;
 }
 
 __device__ __forceinline__ bool project(float x, float y, float z, int ni, int nj, const PassParams &P, float &xs,
@@ -202,7 +206,9 @@ __device__ __forceinline__ bool project(float x, float y, float z, int ni, int n
         dec = asin_small(q);
         ra = atan_small(Y / Z);
     } else {
-        polar_libm(q, Y, Z, dec, ra);
+        const Polar pl = polar_libm(q, Y, Z);
+        dec = pl.dec;
+        ra = pl.ra;
     }
     if (!(fabs(ra) <= P.lim && fabs(dec) <= P.lim))
         return false;  // NaN (d == 0) is rejected, as in the reference
