@@ -417,6 +417,37 @@ def test_full_size_properties_256cubed_4096(S):
     assert 0.70 * n < tot_sel < 0.85 * n  # S8d geometry: ~77 % of the box lands in the four planes
 
 
+def test_baseline_config0_128cubed_256_ngp_bit_exact(S):
+    """BASELINE.json configs[0]: synthetic 128^3 box, 256^2 map, NGP, one snapshot, one plane -- full-map parity."""
+    n = 128 ** 3
+    f = one_type_file(n)
+    ref_tot, ref_toti, nsel = run_oracle([f], 256, 0.25, 3.0, 3.25, ngp=True)
+    (tot, toti, cnt), = run_gpu(S, [f], 256, 0.25, 3.0, 3.25, ngp=True)
+    assert np.array_equal(cnt, nsel) and nsel[1] > 300000
+    assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+    assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
+
+
+def test_baseline_config1_256cubed_1024_tsc_four_planes(S):
+    """BASELINE.json configs[1]: 256^3 particles, 1024^2 TSC, one snapshot -> 4 lens planes in one pass, every
+    plane against the oracle's createDensityMaps for that plane (per-pixel relative bar 2e-6, counts exact)."""
+    n = 256 ** 3
+    f = one_type_file(n)
+    lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
+    out = run_gpu(S, [f], 1024, 0.25, lds, ld2s, device_resident=True)
+    worst = 0.0
+    for p in range(4):
+        ref_tot, _, nsel = run_oracle([f], 1024, 0.25, lds[p], ld2s[p])
+        tot, _, cnt = out[p]
+        assert np.array_equal(cnt, nsel)
+        assert np.array_equal(tot == 0, ref_tot == 0)
+        nz = ref_tot > 0
+        rel = float((np.abs(tot[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max())
+        worst = max(worst, rel)
+    assert worst <= 2e-6, worst
+    print(f"config1: max per-pixel relative difference {worst:.2e}")
+
+
 def test_rccl_plane_reduce_single_rank(S):
     """slicer_amd_rccl.h on a one-rank communicator: the sum over ranks is the identity; exercises the
     ncclReduce call sequence (maps + counters) on the handle's stream.  Multi-rank runs need >1 GPU."""
