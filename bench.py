@@ -119,8 +119,25 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or os.environ.get("SLICER_BENCH_FORCE_DIST") == "1"  # the latter: rehearse on one GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL prints its version banner on STDOUT when the first communicator comes up; the driver reads one JSON
+        # line from stdout, so stdout is pointed at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     n_snap = a.side ** 3
     files = a.files
@@ -168,7 +185,7 @@ def main():
             S.deposit_device(1, pos[s][j].data_ptr(), per_file)
             S.file_end()
         S.plane_finalize()
-        if a.shard == "files" and world > 1:
+        if a.shard == "files" and use_dist:
             # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL reduce over xGMI
             parallel.reduce_planes(S, dist, torch, root=0, per_type=False)
 
@@ -184,21 +201,21 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
     my_dep = sum(dep_per_snap[i % len(my_snaps)] for i in range(a.steps))
     my_in = a.steps * per_file * len(my_files)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -271,9 +288,9 @@ def main():
             "kernels": kernels,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     S.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
