@@ -123,6 +123,12 @@ int slicer_file_begin(slicer_handle h, const slicer_file_desc *file);
 /* pos: AoS [n][3] f32 exactly as in the POS block (raw file units), host memory.  mass: per-particle
  * f32 masses (hydro types with massarr == 0: MASS / BHMA stream, densitymaps.cpp:358-372) or NULL. */
 int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float *mass, uint64_t n);
+/* Same as slicer_deposit_host, but the library pulls the particles: `fill(user, dst_pos, dst_mass, first, count)`
+ * must write particles [first, first+count) of this type straight into the pinned staging buffers it is given
+ * (dst_mass is NULL when has_mass == 0) and return 0; e.g. an fread from the POS block.  Saves the pageable
+ * copy of the whole block and overlaps file reads with H2D and kernels (double-buffered).  SURVEY S8f row N1. */
+typedef int (*slicer_fill_fn)(void *user, float *dst_pos, float *dst_mass, uint64_t first, uint64_t count);
+int slicer_deposit_stream(slicer_handle h, int type, uint64_t n, int has_mass, slicer_fill_fn fill, void *user);
 /* same, operands already resident in this device's HBM */
 int slicer_deposit_device(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n);
 int slicer_file_end(slicer_handle h);

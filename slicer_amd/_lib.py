@@ -37,6 +37,7 @@ SYMBOLS = {
     "slicer_plane_begin": (C.c_int, [_H, C.POINTER(PlaneDesc)]),
     "slicer_file_begin": (C.c_int, [_H, C.POINTER(FileDesc)]),
     "slicer_deposit_host": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "slicer_deposit_stream": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "slicer_deposit_device": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "slicer_file_end": (C.c_int, [_H]),
     "slicer_plane_finalize": (C.c_int, [_H]),

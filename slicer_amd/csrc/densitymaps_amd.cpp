@@ -3,8 +3,10 @@
 #include "densitymaps_amd.hpp"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
+#include <vector>
 
 #include "../../include/slicer_amd.h"
 #include "gadget2_reader.hpp"
@@ -107,8 +109,8 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
             return 1;
         }
         const Header &data = snap.header();
-        std::vector<float> pos;
-        if (!snap.read_block("POS ", pos)) {
+        long pos_off = 0, pos_bytes = 0;
+        if (!snap.locate_block("POS ", pos_off, pos_bytes)) {
             std::cerr << "slicer_amd: no POS block in " << snap.path() << std::endl;
             return 1;
         }
@@ -124,7 +126,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
             f.massarr[t] = data.massarr[t];
             ntot += data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
         }
-        if (pos.size() < 3 * ntot) {
+        if ((size_t)pos_bytes < 12 * ntot) {
             std::cerr << "slicer_amd: POS block of " << snap.path() << " is shorter than the header says" << std::endl;
             return 1;
         }
@@ -141,12 +143,28 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
             std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
             return 1;
         }
+        // The POS block is streamed straight into the library's pinned staging buffers (no pageable copy of the
+        // block): file reads overlap with the H2D copies and kernels of the previous chunk.
+        struct Span {
+            slicer_amd::SnapshotFile *snap;
+            long base;          // file offset of this type's first particle
+            const float *mass;  // or nullptr
+        };
+        auto fill = [](void *user, float *dst_pos, float *dst_mass, uint64_t first, uint64_t count) -> int {
+            Span *s = static_cast<Span *>(user);
+            if (!s->snap->read_at(s->base + (long)(12 * first), dst_pos, (size_t)(12 * count)))
+                return 1;
+            if (dst_mass)
+                std::copy(s->mass + first, s->mass + first + count, dst_mass);
+            return 0;
+        };
         size_t off = 0;
         for (int t = 0; t < 6; t++) {
             const size_t n = data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
             if (n) {
                 const float *m = (p.hydro && data.massarr[t] == 0 && !mass[t].empty()) ? mass[t].data() : nullptr;
-                if (slicer_deposit_host(h, t, pos.data() + 3 * off, m, n) != SLICER_OK) {
+                Span span{&snap, pos_off + (long)(12 * off), m};
+                if (slicer_deposit_stream(h, t, n, m != nullptr, fill, &span) != SLICER_OK) {
                     std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
                     return 1;
                 }

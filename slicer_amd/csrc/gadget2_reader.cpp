@@ -58,6 +58,13 @@ bool SnapshotFile::read_block(const char *name4, std::vector<float> &out)
     return out.empty() || fread(out.data(), sizeof(float), out.size(), f_) == out.size();
 }
 
+bool SnapshotFile::read_at(long offset, void *dst, size_t bytes)
+{
+    if (!f_ || fseek(f_, offset, SEEK_SET) != 0)
+        return false;
+    return bytes == 0 || fread(dst, 1, bytes, f_) == bytes;
+}
+
 bool SnapshotFile::read_masses(std::vector<float> (&mass)[6])
 {
     bool need = false;

@@ -24,6 +24,9 @@ public:
     // Per-type masses of the types with massarr == 0 (densitymaps.cpp:358-372): MASS in type order,
     // type 5 from BHMA.  mass[t] stays empty for types that use massarr.
     bool read_masses(std::vector<float> (&mass)[6]);
+    // Streaming access: where a block's payload starts, and a positioned read of part of it.
+    bool locate_block(const char *name4, long &offset, long &nbytes) { return find_block(name4, offset, nbytes); }
+    bool read_at(long offset, void *dst, size_t bytes);
 
 private:
     bool find_block(const char *name4, long &offset, long &nbytes);

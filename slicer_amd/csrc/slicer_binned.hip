@@ -17,8 +17,6 @@
 //                        global atomic flush of the non-zero cells.
 //
 // Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
-#include <cstdlib>
-
 #include "slicer_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -27,7 +25,6 @@ namespace slicer {
 
 namespace {
 
-constexpr int kBlock = 256;     // scatter workgroup
 constexpr int kK1Block = 512;   // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
 constexpr int kPerThread = 4;
 constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 workgroup
@@ -160,10 +157,7 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
             float x, y, z;
-            if (P.force_libm & 4) {
-                x = rx[k] * 1e-3f; y = ry[k] * 1e-3f; z = rz[k] * 1e-3f + 3.0f;
-            } else
-                transform(rx[k], ry[k], rz[k], P, x, y, z);
+            transform(rx[k], ry[k], rz[k], P, x, y, z);
             const bool live = k < nvalid;
             neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
             // slabs are disjoint on this path (checked on the host); constant indices keep the thresholds in
@@ -204,7 +198,7 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
             if (lane < take) {
                 const float4 ent = q4[e];
                 plane = __float_as_int(ent.w);
-                if (!(P.force_libm & 2) && project(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
+                if (project(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
                     valid = true;
                     int gx = grid_index<POW2>(xs, P);
                     int gy = grid_index<POW2>(ys, P);
@@ -381,7 +375,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__rest
                                                             const unsigned *__restrict__ base,
                                                             const unsigned *__restrict__ bcount, int nblocks,
                                                             BinGeom G, float2 *__restrict__ sxy,
-                                                            float *__restrict__ sm, int dbg)
+                                                            float *__restrict__ sm)
 {
     extern __shared__ unsigned smem_sc[];
     const int tpp = G.tiles_per_plane;
@@ -472,9 +466,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__rest
             const unsigned t = sorted_tile[p];
             // pos0[t] now points past the tile's run: its start is pos0[t] - cnt[t]  (mod 2^16: nsub = 8192 can
             // make the last tile's end 8192, still < 65536, so no wrap)
-            unsigned dst = cur[t] + (p - (get16(pos0, t) - get16(cnt, t)));
-            if (dbg == 2)
-                dst = (unsigned)(brow[0] + row[0]) + s0 + p;  // experiment: fully coalesced store
+            const unsigned dst = cur[t] + (p - (get16(pos0, t) - get16(cnt, t)));
             sxy[dst] = sorted_xy[p];
             if (HAS_MASS)
                 sm[dst] = sorted_m[p];
@@ -509,22 +501,78 @@ __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, 
                   (unsigned long long)__double2ll_rn((double)c * P.fixed_scale));  // ds_add_u64
 }
 
+// Work items of the tile kernel: a (plane, tile) bin with many records (a halo core can put 10^5..10^7
+// particles into one tile) is split into parts of <= kItemRecs records, each deposited by its own workgroup
+// into its own LDS tile and flushed atomically, so that one heavy tile neither serialises on one CU nor
+// stretches the kernel's tail.  Empty bins get no item.
+constexpr unsigned kItemRecs = 16384;
+
+struct TileItems {
+    uint2 *items;      // [max_items] {bin, part}
+    unsigned *nparts;  // [nbins]
+    unsigned *n_items; // [1]
+};
+
+__global__ __launch_bounds__(1024) void k_build_items(PendingList L, int nbins, TileItems I)
+{
+    __shared__ unsigned s_wave[1024 / 64];
+    const int tid = threadIdx.x;
+    const int per = (nbins + 1023) / 1024;
+    unsigned mine = 0;
+    for (int j = 0; j < per; j++) {
+        const int b = tid * per + j;
+        if (b < nbins) {
+            unsigned tot = 0;
+            for (int c = 0; c < L.n; c++)
+                tot += L.base[c][b + 1] - L.base[c][b];
+            const unsigned np = (tot + kItemRecs - 1) / kItemRecs;
+            I.nparts[b] = np;
+            mine += np;
+        }
+    }
+    // exclusive scan over the 1024 lanes (wave scan + wave totals through LDS)
+    unsigned x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = (unsigned)__shfl_up((int)x, d);
+        if ((int)(threadIdx.x & 63) >= d)
+            x += y;
+    }
+    if ((threadIdx.x & 63) == 63)
+        s_wave[tid >> 6] = x;
+    __syncthreads();
+    unsigned off = 0;
+    for (int k = 0; k < (tid >> 6); k++)
+        off += s_wave[k];
+    unsigned e = off + x - mine;
+    for (int j = 0; j < per; j++) {
+        const int b = tid * per + j;
+        if (b < nbins) {
+            const unsigned np = I.nparts[b];
+            for (unsigned q = 0; q < np; q++)
+                I.items[e + q] = make_uint2((unsigned)b, q);
+            e += np;
+        }
+    }
+    if (tid == 1023)
+        *I.n_items = e;
+}
+
 constexpr int kTileBlock = 1024;
 
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
-__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T)
+__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
+                                                             TileItems I)
 {
     using acc_t = typename AccT<ACC>::type;
     using lds_t = typename AccT<ACC>::lds;
     extern __shared__ unsigned char smem_raw[];
     lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
 
-    const unsigned bin = blockIdx.x;
-    unsigned nrec = 0;
-    for (int c = 0; c < L.n; c++)
-        nrec += L.base[c][bin + 1] - L.base[c][bin];
-    if (nrec == 0)
+    if (blockIdx.x >= *I.n_items)
         return;
+    const uint2 item = I.items[blockIdx.x];
+    const unsigned bin = item.x, part = item.y, nparts = I.nparts[bin];
     const int plane = bin / G.tiles_per_plane;
     const int t = bin % G.tiles_per_plane;
     const int x0 = (t % G.ntx) << G.tw_log2;
@@ -540,7 +588,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 
     constexpr int U = 4;  // records in flight per lane
     for (int c = 0; c < L.n; c++) {
-        const unsigned start = L.base[c][bin], end = L.base[c][bin + 1];
+        // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts)
+        const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
+        const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
+        const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
         const float2 *__restrict__ sxy = L.sxy[c];
         const float *__restrict__ sm = L.sm[c];
         const float mconst = L.mconst[c], smc = L.sm_const[c];
@@ -677,7 +728,6 @@ hipError_t launch_bin_scatter(bool has_mass, int nblocks, int n_planes, const Bi
 {
     const size_t lds = scatter_lds_bytes(G, has_mass);
     const int grid = n_planes * 8 * ((nblocks + 7) / 8);
-    static const int dbg = getenv("SLICER_DBG_SCATTER") ? atoi(getenv("SLICER_DBG_SCATTER")) : 0;
     const unsigned short *cb = reinterpret_cast<const unsigned short *>(W.cbin);
     hipError_t e;
     if (has_mass) {
@@ -686,14 +736,14 @@ hipError_t launch_bin_scatter(bool has_mass, int nblocks, int n_planes, const Bi
         if (e != hipSuccess)
             return e;
         k_bin_scatter<true><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                          W.sm, dbg);
+                                                          W.sm);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
         k_bin_scatter<false><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                           W.sm, dbg);
+                                                           W.sm);
     }
     return hipGetLastError();
 }
@@ -706,7 +756,7 @@ size_t tile_lds_bytes(const BinGeom &G, int acc)
 
 template <int MAS, int ACC>
 static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const BinGeom &G, const PendingList &L,
-                            const Targets &T, hipStream_t s)
+                            const Targets &T, const TileItems &I, unsigned max_items, hipStream_t s)
 {
     const size_t lds = tile_lds_bytes(G, ACC);
 #define K4(P2_, HM_)                                                                                             \
@@ -718,7 +768,7 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
             if (e != hipSuccess)                                                                                 \
                 return e;                                                                                        \
         }                                                                                                        \
-        kern<<<G.nbins, kTileBlock, lds, s>>>(L, P, G, T);                                         \
+        kern<<<max_items, kTileBlock, lds, s>>>(L, P, G, T, I);                                         \
     } while (0)
     if (pow2) {
         if (has_mass) K4(true, true); else K4(true, false);
@@ -729,19 +779,32 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
     return hipGetLastError();
 }
 
-hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
-                               const Targets &T, hipStream_t s)
+size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles)
 {
+    const uint64_t max_items = (uint64_t)G.nbins + total_particles / kItemRecs + 1;
+    return max_items * sizeof(uint2) + (size_t)G.nbins * 4 + 16;
+}
+
+hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
+                               const Targets &T, void *items_ws, uint64_t total_particles, hipStream_t s)
+{
+    // total_particles bounds the number of records (each particle emits at most one on this path)
+    const unsigned max_items = (unsigned)((uint64_t)G.nbins + total_particles / kItemRecs + 1);
+    TileItems I;
+    I.items = reinterpret_cast<uint2 *>(items_ws);
+    I.nparts = reinterpret_cast<unsigned *>(I.items + max_items);
+    I.n_items = I.nparts + G.nbins;
+    k_build_items<<<1, 1024, 0, s>>>(L, G.nbins, I);
     const bool pow2 = P.pow2 != 0;
     if (cfg.mas == kNGP) {
         if (cfg.acc == kCountU32)
-            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, s);
-        return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, s);
+            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, max_items, s);
+        return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
     }
     switch (cfg.acc) {
-    case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, s);
-    case kF64: return launch_k4<kTSC, kF64>(pow2, cfg.has_mass, P, G, L, T, s);
-    case kFixed64: return launch_k4<kTSC, kFixed64>(pow2, cfg.has_mass, P, G, L, T, s);
+    case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
+    case kF64: return launch_k4<kTSC, kF64>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
+    case kFixed64: return launch_k4<kTSC, kFixed64>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
     default: return hipErrorInvalidValue;
     }
 }

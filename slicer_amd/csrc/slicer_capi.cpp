@@ -3,6 +3,7 @@
 // Reference behaviour mirrored per entry point is cited in the header.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -74,7 +75,8 @@ struct slicer_handle_s {
     uint64_t stage_cap = 0;  // particles
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
-    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount;
+    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    uint64_t pend_particles = 0;  // particles behind the pending chunks (bounds their record count)
     DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
     // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
     PendingList pend{};
@@ -250,8 +252,7 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
         P.tan_lim_hi = (float)(std::tan(P.lim) * (1.0 + 1e-5));
         P.sin2_lim_hi = (float)(std::sin(P.lim) * std::sin(P.lim) * (1.0 + 1e-5));
     }
-    static const int force_libm = getenv("SLICER_FORCE_LIBM") ? atoi(getenv("SLICER_FORCE_LIBM")) : 0;
-    P.force_libm = force_libm | (d.debug_flags & 1);
+    P.force_libm = d.debug_flags & 1;
     P.nn = d.npix;
     P.pow2 = is_pow2(d.npix) ? 1 : 0;
     P.dl = 1. / double(d.npix);  // utilities.cpp:50
@@ -399,7 +400,11 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     if (nb > kMaxBins)
         return false;
     G.nbins = (int)nb;
-    G.batch = env_b ? env_b : kBinBatch;
+    // tuning overrides (SLICER_TILE_LOG2 / SLICER_TILE_H_LOG2 / SLICER_BIN_BATCH): the batch must be a multiple of
+    // one K1 round (2048 particles) and fit the 16-bit per-workgroup counters
+    G.batch = env_b ? std::min(std::max((env_b / 2048) * 2048, 2048), 32768) : kBinBatch;
+    if (G.tw_log2 < 3 || G.tw_log2 > 8 || G.th_log2 < 3 || G.th_log2 > 8)
+        return false;
     return true;
 }
 
@@ -434,12 +439,17 @@ int flush_pending(slicer_handle h)
 {
     if (h->pend.n == 0)
         return SLICER_OK;
+    int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles));
+    if (rc)
+        return rc;
     {
         ProfScope ps(h, KN_TILE);
-        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, h->stream));
+        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, h->w_items.p,
+                                      h->pend_particles, h->stream));
     }
     h->pend.n = 0;
     h->pend_key = -1;
+    h->pend_particles = 0;
     return SLICER_OK;
 }
 
@@ -497,6 +507,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     h->pend.mconst[slot] = P.mconst;
     h->pend.sm_const[slot] = P.sm_const;
     h->pend.n = slot + 1;
+    h->pend_particles += n;
     return SLICER_OK;
 }
 
@@ -617,7 +628,7 @@ int slicer_destroy(slicer_handle h)
             release(pl.acc[t]);
         }
     }
-    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount})
+    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items})
         release(*b);
     for (int i = 0; i < kMaxPending; i++) {
         release(h->w_sxy[i]);
@@ -680,6 +691,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     h->fixed_shared_set = false;
     h->pend.n = 0;
     h->pend_key = -1;
+    h->pend_particles = 0;
     for (int t = 0; t < 6; t++) {
         h->type_seen[t] = false;
         h->fixed_exp_set[t] = false;
@@ -741,30 +753,48 @@ int slicer_deposit_device(slicer_handle h, int type, const float *d_pos, const f
     return SLICER_OK;
 }
 
-int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float *mass, uint64_t n)
+namespace {
+struct HostSpan {
+    const float *pos;
+    const float *mass;
+};
+int copy_fill(void *user, float *dst_pos, float *dst_mass, uint64_t first, uint64_t count)
 {
-    int rc = check_deposit_args(h, type, pos, mass, n);
+    const HostSpan *s = static_cast<const HostSpan *>(user);
+    memcpy(dst_pos, s->pos + 3 * first, count * 12);
+    if (dst_mass)
+        memcpy(dst_mass, s->mass + first, count * 4);
+    return 0;
+}
+}  // namespace
+
+int slicer_deposit_stream(slicer_handle h, int type, uint64_t n, int has_mass, slicer_fill_fn fill, void *user)
+{
+    int rc = check_deposit_args(h, type, fill ? (const void *)h : nullptr, nullptr, n);
     if (rc)
         return rc;
     if (n == 0)
         return SLICER_OK;
+    if (!fill)
+        return fail(h, SLICER_ERR_ARG, "null fill callback");
     HIPCHK(h, hipSetDevice(h->device));
-    rc = begin_type(h, type, mass != nullptr);
+    rc = begin_type(h, type, has_mass != 0);
     if (rc)
         return rc;
-    rc = ensure_staging(h, mass != nullptr);
+    rc = ensure_staging(h, has_mass != 0);
     if (rc)
         return rc;
     int slot = 0;
     for (uint64_t off = 0; off < n; off += h->stage_cap, slot ^= 1) {
         uint64_t c = std::min<uint64_t>(h->stage_cap, n - off);
-        // the slot is reusable once the kernel that read it has finished
+        // the slot is reusable once the kernel that read it has finished; meanwhile the other slot's
+        // H2D copy and kernels run, so filling (file read) overlaps with device work
         HIPCHK(h, hipEventSynchronize(h->stage_free[slot]));
-        memcpy(h->h_stage[slot], pos + 3 * off, c * 12);
+        if (fill(user, h->h_stage[slot], has_mass ? h->h_mstage[slot] : nullptr, off, c) != 0)
+            return fail(h, SLICER_ERR_ARG, "fill callback failed at particle %llu", (unsigned long long)off);
         HIPCHK(h, hipMemcpyAsync(h->d_stage[slot], h->h_stage[slot], c * 12, hipMemcpyHostToDevice, h->stream));
         const float *dm = nullptr;
-        if (mass) {
-            memcpy(h->h_mstage[slot], mass + off, c * 4);
+        if (has_mass) {
             HIPCHK(h, hipMemcpyAsync(h->d_mstage[slot], h->h_mstage[slot], c * 4, hipMemcpyHostToDevice, h->stream));
             dm = h->d_mstage[slot];
         }
@@ -774,6 +804,15 @@ int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float
         HIPCHK(h, hipEventRecord(h->stage_free[slot], h->stream));
     }
     return SLICER_OK;
+}
+
+int slicer_deposit_host(slicer_handle h, int type, const float *pos, const float *mass, uint64_t n)
+{
+    int rc = check_deposit_args(h, type, pos, mass, n);
+    if (rc)
+        return rc;
+    HostSpan span{pos, mass};
+    return slicer_deposit_stream(h, type, n, mass != nullptr, copy_fill, &span);
 }
 
 int slicer_file_end(slicer_handle h)

@@ -89,7 +89,8 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
                                           float &z)
 {
     double qx = (double)rx * P.inv_box, qy = (double)ry * P.inv_box, qz = (double)rz * P.inv_box;
-    if (__ballot(box_quotient_risky(qx) | box_quotient_risky(qy) | box_quotient_risky(qz)) != 0ull) {
+    const int risky = (int)box_quotient_risky(qx) | (int)box_quotient_risky(qy) | (int)box_quotient_risky(qz);
+    if (__ballot(risky != 0) != 0ull) {
         qx = div_by_box_exact(rx, P.box, qx);  // wave-uniform branch, p ~ 1e-5 per wave
         qy = div_by_box_exact(ry, P.box, qy);
         qz = div_by_box_exact(rz, P.box, qz);
