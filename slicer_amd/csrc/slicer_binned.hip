@@ -275,16 +275,17 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a: per bin, exclusive prefix over workgroups (in place) + total.  One 256-thread workgroup owns
-// 16 bins x 16 segments of the workgroup axis: segment sums, a 16-way scan in LDS, then the prefix write.
+// K2a: per bin, exclusive prefix over workgroups + total: segment sums, a 16-way scan in LDS, prefix write.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan_blocks(const unsigned short *__restrict__ hist16,
-                                                     unsigned *__restrict__ prefix, unsigned *__restrict__ total,
-                                                     int nblocks, int nbins)
+__global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__restrict__ hist16,
+                                                      unsigned *__restrict__ prefix, unsigned *__restrict__ total,
+                                                      int nblocks, int nbins)
 {
-    __shared__ unsigned s_seg[16][17];
-    const int bl = threadIdx.x & 15, seg = threadIdx.x >> 4;
-    const int bin = blockIdx.x * 16 + bl;
+    // 64 bins (one per lane: a wave reads 128 contiguous bytes of a histogram row) x 16 segments of the
+    // workgroup axis (one per wave)
+    __shared__ unsigned s_seg[16][64];
+    const int bl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + bl;
     const size_t stride16 = (size_t)((nbins + 1) >> 1) * 2;
     const int per = (nblocks + 15) / 16;
     const int lo = seg * per, hi = lo + per < nblocks ? lo + per : nblocks;
@@ -711,7 +712,7 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
 
 hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
 {
-    k_scan_blocks<<<(G.nbins + 15) / 16, 256, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
+    k_scan_blocks<<<(G.nbins + 63) / 64, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
                                                          nblocks, G.nbins);
     k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins);
     return hipGetLastError();
