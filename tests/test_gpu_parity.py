@@ -474,6 +474,28 @@ def test_heavy_tile_is_split_and_stays_exact(S):
     assert float(rel.max()) < 2 * (n // 2) * 2.0 ** -24
 
 
+@pytest.mark.parametrize("name", __import__("golden_util").names())
+@pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
+def test_golden_vectors(S, name, algo):
+    """The HIP path against the committed fixtures of tests/golden/ (no oracle call at run time)."""
+    import golden_util
+    files, c, tot, toti, nsel = golden_util.load(name)
+    (g_tot, g_toti, g_cnt), = run_gpu(S, files, c["npix"], c["fov"], c["ld"], c["ld2"], ngp=c["ngp"], algo=algo,
+                                      nrep=c["nrep"], hydro=c["hydro"], rnd=c["rnd"])
+    assert np.array_equal(g_cnt, nsel)
+    exact = c["ngp"] and not c["hydro"]
+    for got, ref in [(g_tot, tot)] + [(g_toti[t], toti[t]) for t in range(6)]:
+        if exact:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        else:
+            assert np.array_equal(got == 0, ref == 0)
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            assert np.all(d <= 2e-6 * ref)
+    if c["ngp"] and c["hydro"]:  # constant-mass species stay bit-exact under NGP even in a hydro run
+        for t in (1, 2, 3, 5):
+            assert np.array_equal(g_toti[t].view(np.uint32), toti[t].view(np.uint32))
+
+
 def test_rccl_plane_reduce_single_rank(S):
     """slicer_amd_rccl.h on a one-rank communicator: the sum over ranks is the identity; exercises the
     ncclReduce call sequence (maps + counters) on the handle's stream.  Multi-rank runs need >1 GPU."""
