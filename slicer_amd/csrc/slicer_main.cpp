@@ -1,0 +1,333 @@
+// slicer_main.cpp -- `SLICER_amd InputParams.ini`: the Gadget branch of slicer-v2.cpp (:23-229) on one MI355X, without
+// MPI.  Planning (planner.cpp) -> plane loop -> createDensityMaps-equivalent passes over the C ABI -> writeMaps.
+// Differences from the reference driver, all opt-out:
+//   * the planes cut from one box replication (same snapshot, same Random entry, same rcase) are built in ONE pass
+//     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
+//   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
+//     partinplanes runs write their per-type files;                                      --reference-counts disables
+//   * SubFind / halo-catalogue mode (npix == 0) and snopt > 0 are not supported.
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <valarray>
+#include <vector>
+
+#include "../../include/slicer_amd.h"
+#include "fits_writer.hpp"
+#include "gadget2_reader.hpp"
+#include "planner.hpp"
+
+using namespace slicer_amd;
+using std::cerr;
+using std::cout;
+using std::endl;
+using std::string;
+using std::vector;
+
+namespace {
+
+bool file_exists(const string &p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+string plane_label(int pll)  // slicer-v2.cpp:154-159
+{
+    char b[16];
+    snprintf(b, sizeof b, "%i", pll);
+    if (pll < 10)
+        return string("00") + b;
+    if (pll < 100)
+        return string("0") + b;
+    return b;
+}
+
+void dump_plan(const string &path, const InputParams &p, const Lens &lens, const Random &random,
+               const vector<double> &snapbox, double fovradiants)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f)
+        return;
+    fprintf(f, "{\n \"Ds\": %.17g, \"fovradiants\": %.17g, \"nplanes\": %d, \"hydro\": %d,\n \"planes\": [\n", p.Ds,
+            fovradiants, lens.nplanes, (int)p.hydro);
+    for (int i = 0; i < lens.nplanes; i++) {
+        fprintf(f,
+                "  {\"ld\": %.17g, \"ld2\": %.17g, \"zsimlens\": %.17g, \"fromsnap\": \"%s\", \"fromsnapi\": %d, "
+                "\"randomize\": %d, \"replication\": %d, \"nrepperp\": %d, \"snapbox\": %.17g, \"x0\": %.17g, \"y0\": %.17g, "
+                "\"z0\": %.17g, \"face\": %d, \"sgn\": [%d, %d, %d]}%s\n",
+                lens.ld[i], lens.ld2[i], lens.zsimlens[i], lens.fromsnap[i].c_str(), lens.fromsnapi[i],
+                (int)lens.randomize[i], lens.replication[i], lens.nrepperp[i], snapbox[lens.fromsnapi[i]], random.x0[i],
+                random.y0[i], random.z0[i], random.face[i], random.sgnX[i], random.sgnY[i], random.sgnZ[i],
+                i + 1 < lens.nplanes ? "," : "");
+    }
+    fprintf(f, " ]\n}\n");
+    fclose(f);
+}
+
+struct Span {
+    SnapshotFile *snap;
+    long base;
+    const float *mass;
+};
+int fill_from_file(void *user, float *dst_pos, float *dst_mass, uint64_t first, uint64_t count)
+{
+    Span *s = static_cast<Span *>(user);
+    if (!s->snap->read_at(s->base + (long)(12 * first), dst_pos, (size_t)(12 * count)))
+        return 1;
+    if (dst_mass)
+        std::copy(s->mass + first, s->mass + first + count, dst_mass);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    string inifile, plan_path;
+    int device = 0, mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32;
+    bool plan_only = false, single_plane = false, reference_counts = false, replication = false;
+    for (int i = 1; i < argc; i++) {
+        string a = argv[i];
+        if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--ngp") mas = SLICER_MAS_NGP;
+        else if (a == "--accum" && i + 1 < argc) {
+            string v = argv[++i];
+            accum = v == "f64" ? SLICER_ACC_F64 : (v == "fixed64" ? SLICER_ACC_FIXED64 : SLICER_ACC_F32);
+        } else if (a == "--plan-only") plan_only = true;
+        else if (a == "--dump-plan" && i + 1 < argc) plan_path = argv[++i];
+        else if (a == "--single-plane") single_plane = true;
+        else if (a == "--reference-counts") reference_counts = true;
+        else if (a == "--replication") replication = true;  // -DUSE_REPLICATION (ReplicationOnPerpendicularPlane)
+        else if (inifile.empty()) inifile = a;
+        else {
+            cerr << "unknown argument " << a << endl;
+            return 2;
+        }
+    }
+    if (inifile.empty()) {
+        cout << "No params!! Nothing to be done!" << endl;  // slicer-v2.cpp:34
+        return 2;
+    }
+    const int myid = 0;
+    InputParams p{};
+    double fovradiants = 0;
+    if (readInput(p, inifile))
+        return 1;
+    if (p.simType == "SubFind") {
+        cerr << "SubFind / halo light-cone mode (npix == 0) is outside this driver's scope" << endl;
+        return 1;
+    }
+    vector<string> snappath;
+    vector<double> snapred, snapbox;
+    if (readRedList(p.filredshiftlist, snapred, snappath, snapbox, p))
+        return 1;
+    Header simdata{};
+    {
+        SnapshotFile s0;
+        if (!s0.open(p.pathsnap + snappath[0] + ".0")) {
+            cerr << "Error in opening the file: " << p.pathsnap + snappath[0] + ".0" << "!\n\a";
+            return 1;
+        }
+        simdata = s0.header();
+    }
+    testHydro(p, simdata);
+
+    // slicer-v2.cpp:79-96: distance table (h = 1) and the two interpolators
+    w0waCDM cosmo(100.0, simdata.om0, simdata.oml, p.w, 0.0);
+    vector<double> zl(kNeval), dl(kNeval);
+    for (int i = 0; i < kNeval; i++) {
+        zl[i] = i * (p.zs + 1.0) / (kNeval - 1);
+        dl[i] = cosmo.transverseComovingDistance(zl[i]);
+    }
+    NaturalCubicSpline getDl, getZl;
+    getDl.init(zl, dl);
+    getZl.init(dl, zl);
+    p.Ds = getDl.eval(p.zs);
+
+    Lens lens{};
+    if (buildPlanes(p, lens, snapred, snappath, snapbox, getDl, getZl, kNumberOfLensPerSnap, myid))
+        return 1;
+    lens.nrepperp.resize(lens.ld.size(), 0);
+    for (size_t i = 0; i < lens.ld.size(); i++) {  // slicer-v2.cpp:103-125
+        if (!replication) {
+            if (testFov(p.fov, snapbox[lens.fromsnapi[i]] / 1e3 * kPosU, lens.ld2[i], myid, fovradiants))
+                return 1;
+        } else {
+            computeReplications(p.fov, snapbox[lens.fromsnapi[i]] / 1e3 * kPosU, lens.ld2[i], myid, fovradiants,
+                                lens.nrepperp[i]);
+        }
+    }
+    Random random;
+    randomizeBox(random, lens, p, kNumberOfLensPerSnap, myid);
+    if (!plan_path.empty())
+        dump_plan(plan_path, p, lens, random, snapbox, fovradiants);
+    if (plan_only)
+        return 0;
+    if (p.snopt != 0) {
+        cerr << "snopt > 0 (shot-noise thinning through libc rand()) is not supported on the device path" << endl;
+        return 1;
+    }
+
+    slicer_handle h = nullptr;
+    if (slicer_create(device, 1ull << 24, &h) != SLICER_OK) {
+        cerr << "slicer_amd: " << slicer_last_error(nullptr) << endl;
+        return 1;
+    }
+    cout << " Now loop on " << lens.nplanes << " planes " << endl;
+    float rcase = 0.0f;  // slicer-v2.cpp:137
+    int isnap = 0;
+    int rc_all = 0;
+    while (isnap < lens.nplanes && rc_all == 0) {
+        // planes isnap .. iend-1 share snapshot, Random entry and rcase
+        int iend = isnap + 1;
+        if (!single_plane && !p.physical)
+            while (iend < lens.nplanes && iend - isnap < SLICER_MAX_PLANES && !lens.randomize[iend] &&
+                   lens.fromsnapi[iend] == lens.fromsnapi[isnap] && lens.nrepperp[iend] == lens.nrepperp[isnap])
+                iend++;
+        if (p.physical)  // slicer-v2.cpp:142-143
+            p.npix = int((lens.ld2[isnap] + lens.ld[isnap]) / 2 * fovradiants / p.rgrid * 1e3 / kPosU) + 1;
+        const string File = p.pathsnap + lens.fromsnap[isnap];
+        if (lens.randomize[isnap])  // slicer-v2.cpp:184-185
+            rcase = (float)(lens.ld[isnap] / snapbox[lens.fromsnapi[isnap]] * 1e3 / kPosU);
+        for (int i = isnap + 1; i < iend; i++)
+            if (lens.randomize[i])
+                throw std::logic_error("plane grouping crossed a randomisation boundary");
+
+        // resume: planes whose output exists are skipped (slicer-v2.cpp:188-202, only when !partinplanes)
+        vector<int> todo;
+        for (int i = isnap; i < iend; i++) {
+            const string snappl = plane_label(lens.pll[i]);
+            if (!p.partinplanes && file_exists(fileOutput(p, snappl))) {
+                cout << fileOutput(p, snappl) << " Already exists" << endl;
+                continue;
+            }
+            todo.push_back(i);
+        }
+        if (p.partinplanes && isnap == 0)
+            cout << "!It is not possible to resume a Gadget run with partinplanes == true!" << endl;
+        if (todo.empty()) {
+            isnap = iend;
+            continue;
+        }
+        SnapshotFile first;
+        if (!first.open(File + ".0")) {
+            cerr << "Error in opening the file: " << File + ".0" << "!\n\a";
+            rc_all = 1;
+            break;
+        }
+        const Header simhdr = first.header();
+        first.close();
+
+        slicer_plane_desc d{};
+        d.npix = p.npix;
+        d.n_planes = (int)todo.size();
+        d.mas = mas;
+        d.accum = accum;
+        d.hydro = p.hydro;
+        d.snopt = 0;
+        d.want_type_maps = p.partinplanes ? 1 : 0;
+        d.fov_rad = fovradiants;
+        for (size_t k = 0; k < todo.size(); k++) {
+            d.ld[k] = lens.ld[todo[k]];
+            d.ld2[k] = lens.ld2[todo[k]];
+            d.nrepperp[k] = lens.nrepperp[todo[k]];
+        }
+        if (slicer_plane_begin(h, &d) != SLICER_OK) {
+            cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+            rc_all = 1;
+            break;
+        }
+        for (int ff = 0; ff < simhdr.numfiles && rc_all == 0; ff++) {
+            char suffix[32];
+            snprintf(suffix, sizeof suffix, "%i", ff);
+            SnapshotFile snap;
+            if (!snap.open(File + "." + suffix)) {
+                cerr << "Error in opening the file: " << File << "." << suffix << "!\n\a";
+                rc_all = 1;
+                break;
+            }
+            const Header &data = snap.header();
+            long pos_off = 0, pos_bytes = 0;
+            vector<float> mass[6];
+            if (!snap.locate_block("POS ", pos_off, pos_bytes) || (p.hydro && !snap.read_masses(mass))) {
+                cerr << "slicer_amd: cannot read POS / MASS of " << snap.path() << endl;
+                rc_all = 1;
+                break;
+            }
+            slicer_file_desc f{};
+            for (int t = 0; t < 6; t++) {
+                f.npart[t] = data.npart[t];
+                f.massarr[t] = data.massarr[t];
+            }
+            f.boxsize = data.boxsize;
+            f.sgn[0] = random.sgnX[isnap];
+            f.sgn[1] = random.sgnY[isnap];
+            f.sgn[2] = random.sgnZ[isnap];
+            f.face = random.face[isnap];
+            f.center[0] = random.x0[isnap];
+            f.center[1] = random.y0[isnap];
+            f.center[2] = random.z0[isnap];
+            f.rcase = rcase;
+            if (slicer_file_begin(h, &f) != SLICER_OK) {
+                cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+                rc_all = 1;
+                break;
+            }
+            size_t off = 0;
+            for (int t = 0; t < 6 && rc_all == 0; t++) {
+                const size_t n = data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
+                if (n) {
+                    const float *m = (p.hydro && data.massarr[t] == 0 && !mass[t].empty()) ? mass[t].data() : nullptr;
+                    Span span{&snap, pos_off + (long)(12 * off), m};
+                    if (slicer_deposit_stream(h, t, n, m != nullptr, fill_from_file, &span) != SLICER_OK) {
+                        cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+                        rc_all = 1;
+                    }
+                }
+                off += n;
+            }
+            if (rc_all == 0 && slicer_file_end(h) != SLICER_OK) {
+                cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+                rc_all = 1;
+            }
+        }
+        if (rc_all)
+            break;
+        const size_t np2 = (size_t)p.npix * (size_t)p.npix;
+        std::valarray<float> tot(np2), toti[6];
+        vector<float> toti_flat(p.partinplanes ? 6 * np2 : 0);
+        for (size_t k = 0; k < todo.size() && rc_all == 0; k++) {
+            const int i = todo[k];
+            int64_t nsel[6];
+            if (slicer_plane_read(h, (int)k, &tot[0], p.partinplanes ? toti_flat.data() : nullptr, nsel) != SLICER_OK) {
+                cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+                rc_all = 1;
+                break;
+            }
+            int ntotxyi[6];
+            for (int t = 0; t < 6; t++) {
+                ntotxyi[t] = reference_counts ? 0 : (int)nsel[t];
+                if (p.partinplanes) {
+                    toti[t].resize(np2);
+                    std::copy(toti_flat.begin() + t * np2, toti_flat.begin() + (t + 1) * np2, &toti[t][0]);
+                }
+            }
+            const double zsim = getZl.eval((lens.ld2[i] + lens.ld[i]) / 2.0);  // slicer-v2.cpp:219
+            Header hd = simhdr;
+            try {
+                writeMaps(p, hd, lens, i, zsim, plane_label(lens.pll[i]), p.snpix, tot, toti, ntotxyi, myid);
+            } catch (const std::runtime_error &) {
+                rc_all = 1;
+            }
+        }
+        isnap = iend;
+    }
+    slicer_destroy(h);
+    return rc_all;
+}
