@@ -115,45 +115,50 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
 // < 3.5 % of the result the Horner rounding stays below 0.02 ulp, so the value is within ~0.52 ulp (asin)
 // and ~1.02 ulp (atan, including the rounding of the quotient y/z) of the exact one -- the accuracy class
 // of glibc's and OCML's routines, which are used outside that range.  A1..A15 = (2k)!/(4^k k!^2 (2k+1)).
+// Both polynomials are evaluated as two interleaved Horner chains in w = z^2 (even and odd coefficients), which
+// halves the dependent-FMA depth; the series value is p = pe(w) + z*po(w).
 __device__ __forceinline__ double asin_small(double x)
 {
-    const double z = x * x;
-    double p = 0x1.31683bdef7bdfp-8;
-    p = fma(p, z, 0x1.51ba308d3dcb1p-8);
-    p = fma(p, z, 0x1.782dda12f684cp-8);
-    p = fma(p, z, 0x1.a6863d70a3d71p-8);
-    p = fma(p, z, 0x1.df3bd37a6f4dfp-8);
-    p = fma(p, z, 0x1.12ef3cf3cf3cfp-7);
-    p = fma(p, z, 0x1.3fde50d79435ep-7);
-    p = fma(p, z, 0x1.7a87878787878p-7);
-    p = fma(p, z, 0x1.c99999999999ap-7);
-    p = fma(p, z, 0x1.1c4ec4ec4ec4fp-6);
-    p = fma(p, z, 0x1.6e8ba2e8ba2e9p-6);
-    p = fma(p, z, 0x1.f1c71c71c71c7p-6);
-    p = fma(p, z, 0x1.6db6db6db6db7p-5);
-    p = fma(p, z, 0x1.3333333333333p-4);
-    p = fma(p, z, 0x1.5555555555555p-3);
+    const double z = x * x, w = z * z;
+    // A1..A15 split: even-index chain (A1, A3, ..., A15) and odd-index chain (A2, A4, ..., A14)
+    double pe = 0x1.31683bdef7bdfp-8;                 // A15
+    double po = 0x1.51ba308d3dcb1p-8;                 // A14
+    pe = fma(pe, w, 0x1.782dda12f684cp-8);            // A13
+    po = fma(po, w, 0x1.a6863d70a3d71p-8);            // A12
+    pe = fma(pe, w, 0x1.df3bd37a6f4dfp-8);            // A11
+    po = fma(po, w, 0x1.12ef3cf3cf3cfp-7);            // A10
+    pe = fma(pe, w, 0x1.3fde50d79435ep-7);            // A9
+    po = fma(po, w, 0x1.7a87878787878p-7);            // A8
+    pe = fma(pe, w, 0x1.c99999999999ap-7);            // A7
+    po = fma(po, w, 0x1.1c4ec4ec4ec4fp-6);            // A6
+    pe = fma(pe, w, 0x1.6e8ba2e8ba2e9p-6);            // A5
+    po = fma(po, w, 0x1.f1c71c71c71c7p-6);            // A4
+    pe = fma(pe, w, 0x1.6db6db6db6db7p-5);            // A3
+    po = fma(po, w, 0x1.3333333333333p-4);            // A2
+    pe = fma(pe, w, 0x1.5555555555555p-3);            // A1
+    const double p = fma(po, z, pe);                  // A1 + A2 z + A3 z^2 + ...
     return fma(x * z, p, x);
 }
 
 __device__ __forceinline__ double atan_small(double t)
 {
-    const double z = t * t;
-    double p = -0x1.0842108421084p-5;
-    p = fma(p, z, 0x1.1a7b9611a7b96p-5);
-    p = fma(p, z, -0x1.2f684bda12f68p-5);
-    p = fma(p, z, 0x1.47ae147ae147bp-5);
-    p = fma(p, z, -0x1.642c8590b2164p-5);
-    p = fma(p, z, 0x1.8618618618618p-5);
-    p = fma(p, z, -0x1.af286bca1af28p-5);
-    p = fma(p, z, 0x1.e1e1e1e1e1e1ep-5);
-    p = fma(p, z, -0x1.1111111111111p-4);
-    p = fma(p, z, 0x1.3b13b13b13b14p-4);
-    p = fma(p, z, -0x1.745d1745d1746p-4);
-    p = fma(p, z, 0x1.c71c71c71c71cp-4);
-    p = fma(p, z, -0x1.2492492492492p-3);
-    p = fma(p, z, 0x1.999999999999ap-3);
-    p = fma(p, z, -0x1.5555555555555p-2);
+    const double z = t * t, w = z * z;
+    double pe = -0x1.0842108421084p-5;                // -1/31
+    double po = 0x1.1a7b9611a7b96p-5;                 // +1/29
+    pe = fma(pe, w, -0x1.2f684bda12f68p-5);           // -1/27
+    po = fma(po, w, 0x1.47ae147ae147bp-5);            // +1/25
+    pe = fma(pe, w, -0x1.642c8590b2164p-5);           // -1/23
+    po = fma(po, w, 0x1.8618618618618p-5);            // +1/21
+    pe = fma(pe, w, -0x1.af286bca1af28p-5);           // -1/19
+    po = fma(po, w, 0x1.e1e1e1e1e1e1ep-5);            // +1/17
+    pe = fma(pe, w, -0x1.1111111111111p-4);           // -1/15
+    po = fma(po, w, 0x1.3b13b13b13b14p-4);            // +1/13
+    pe = fma(pe, w, -0x1.745d1745d1746p-4);           // -1/11
+    po = fma(po, w, 0x1.c71c71c71c71cp-4);            // +1/9
+    pe = fma(pe, w, -0x1.2492492492492p-3);           // -1/7
+    po = fma(po, w, 0x1.999999999999ap-3);            // +1/5
+    pe = fma(pe, w, -0x1.5555555555555p-2);           // -1/3
+    const double p = fma(po, z, pe);
     return fma(t * z, p, t);
 }
 
