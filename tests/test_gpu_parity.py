@@ -496,6 +496,37 @@ def test_golden_vectors(S, name, algo):
             assert np.array_equal(g_toti[t].view(np.uint32), toti[t].view(np.uint32))
 
 
+def test_large_maps_8192_ngp_exact_and_16384_properties(S):
+    """BASELINE configs[4] shape (16384^2): more than 8192 (plane, tile) bins, so the deposit takes the fused
+    global-atomic kernel; 8192^2 still runs the binned path.  NGP at 8192^2 is compared bit for bit with the
+    oracle; at 16384^2 (1 GiB per map) the checks are size-independent: counts equal the 8192^2 run's (the
+    selection does not depend on npix beyond the 1-pixel FOV margin), integer NGP mass, TSC mass conservation."""
+    n = 200000
+    f = one_type_file(n, m=0.25)
+    ref_tot, _, nsel = run_oracle([f], 8192, 0.25, 3.0, 4.0, ngp=True)
+    S.plane_begin(8192, 0.25, [3.0], [4.0], mas=slicer_amd.MAS_NGP, want_type_maps=True)
+    S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    S.deposit_host(1, f["pos"])
+    S.file_end()
+    tot, _, cnt = S.plane_read(0, want_types=False)
+    assert np.array_equal(cnt, nsel)
+    assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+    del ref_tot, tot
+    for mas in (slicer_amd.MAS_NGP, slicer_amd.MAS_TSC):
+        S.plane_begin(16384, 0.25, [3.0], [4.0], mas=mas, want_type_maps=False, accum=slicer_amd.ACC_F64)
+        S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        S.deposit_host(1, f["pos"])
+        S.file_end()
+        big, _, cnt16 = S.plane_read(0, want_types=False)
+        total = float(big.sum(dtype=np.float64))
+        assert abs(int(cnt16[1]) - int(nsel[1])) <= 0.001 * nsel[1]
+        if mas == slicer_amd.MAS_NGP:
+            assert total / 0.25 == round(total / 0.25) and 0.99 * cnt16[1] <= total / 0.25 <= cnt16[1]
+        else:
+            assert 0.999 * cnt16[1] * 0.25 <= total <= cnt16[1] * 0.25 * (1 + 1e-6)
+        del big
+
+
 def test_rccl_plane_reduce_single_rank(S):
     """slicer_amd_rccl.h on a one-rank communicator: the sum over ranks is the identity; exercises the
     ncclReduce call sequence (maps + counters) on the handle's stream.  Multi-rank runs need >1 GPU."""
