@@ -61,6 +61,10 @@ __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
 // Whenever the stack holds >= 64 entries the wave pops 64 and runs the fp64 projection on a full wave.
 // There is no workgroup barrier in the loop; waves only share the histogram and the output cursor.
 // ---------------------------------------------------------------------------------------------
+#ifndef SLICER_K1_PREFETCH
+#define SLICER_K1_PREFETCH 1
+#endif
+constexpr bool kPrefetch = SLICER_K1_PREFETCH != 0;
 constexpr int kWaves = kK1Block / 64;
 constexpr int kWaveQ = 64 * kPerThread + 64;  // stack capacity per wave: one round + a remainder < 64
 
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
         const uint64_t i1 = i0 + kRound;
         const bool more = r0 + kRound < b1;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
-        if (more)
+        if (kPrefetch && more)
             load_round<VEC, HAS_MASS>(pos, mass, i1, nvalid1, nx, ny, nz, nm);
 
         // ---- transform, slab select, conservative FOV pre-test, push ----
@@ -247,14 +251,18 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
         }
         lds_fence();
 
-        // rotate the prefetched round in
+        // rotate the prefetched round in (or load it now)
+        if (kPrefetch) {
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            rx[k] = nx[k];
-            ry[k] = ny[k];
-            rz[k] = nz[k];
-            if (HAS_MASS)
-                rm[k] = nm[k];
+            for (int k = 0; k < kPerThread; k++) {
+                rx[k] = nx[k];
+                ry[k] = ny[k];
+                rz[k] = nz[k];
+                if (HAS_MASS)
+                    rm[k] = nm[k];
+            }
+        } else if (more) {
+            load_round<VEC, HAS_MASS>(pos, mass, i1, nvalid1, rx, ry, rz, rm);
         }
         i0 = i1;
         nvalid = nvalid1;
