@@ -54,6 +54,12 @@ def lib():
                                               C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_double, C.c_double, C.c_float,
                                               _fp, _fp, np.ctypeslib.ndpointer(dtype=np.int64)]
+        L.orc_create_density_maps_sn.restype = C.c_int
+        L.orc_create_density_maps_sn.argtypes = [C.POINTER(OrcFile), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, C.c_int, C.c_double,
+                                                 C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, C.c_double, C.c_float,
+                                                 _fp, _fp, np.ctypeslib.ndpointer(dtype=np.int64)]
         L.orc_file_range.restype = None
         L.orc_file_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.orc_reduce_sum.restype = None
@@ -114,7 +120,7 @@ def gridist_w(xs, ys, ws, nn, do_ngp):
 
 
 def create_density_maps(files, ffmin, ffmax, npix, hydro, do_ngp, ld, ld2, nrepperp, fov,
-                        sgn, face, center, rcase):
+                        sgn, face, center, rcase, snopt=0):
     """A5 (densitymaps.cpp:419-524). files: list of dicts {npart[6], massarr[6], boxsize, pos[n,3], mass{t:arr}}.
     Returns rc, tot[npix,npix], toti[6,npix,npix], nsel[6]."""
     arr = (OrcFile * len(files))()
@@ -139,8 +145,8 @@ def create_density_maps(files, ffmin, ffmax, npix, hydro, do_ngp, ld, ld2, nrepp
     tot = np.empty(npix * npix, np.float32)
     toti = np.empty(6 * npix * npix, np.float32)
     nsel = np.zeros(6, np.int64)
-    rc = lib().orc_create_density_maps(arr, int(ffmin), int(ffmax), int(npix), int(bool(hydro)), int(bool(do_ngp)),
-                                       float(ld), float(ld2), int(nrepperp), float(fov),
+    rc = lib().orc_create_density_maps_sn(arr, int(ffmin), int(ffmax), int(npix), int(bool(hydro)), int(bool(do_ngp)),
+                                          int(snopt), float(ld), float(ld2), int(nrepperp), float(fov),
                                        int(sgn[0]), int(sgn[1]), int(sgn[2]), int(face),
                                        float(center[0]), float(center[1]), float(center[2]), np.float32(rcase),
                                        tot, toti, nsel)

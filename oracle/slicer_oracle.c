@@ -126,13 +126,28 @@ int orc_min_guard(const float *x, const float *y, const float *z, int64_t n)
 
 /* ---- densitymaps.cpp:346-401  slab select + projection + FOV test -----
  * mass: per-particle masses (hydro type with massarr==0) or NULL -> mconst.
- * Output arrays must hold n*(2*nrep+1)^2 entries.  snopt==0 only.
+ * Output arrays must hold n*(2*nrep+1)^2 entries.  snopt > 0 draws libc rand() per selected entry (:387-397).
  * sel_index (nullable) receives the input index of each selected entry.   */
+int64_t orc_select_project_sn(const float *x, const float *y, const float *z,
+                              const float *mass, float mconst, int64_t n,
+                              double ld, double ld2, double boxsize, int nrep,
+                              double fov, int npix, int snopt,
+                              float *xs, float *ys, float *ms, int64_t *sel_index);
+
 int64_t orc_select_project(const float *x, const float *y, const float *z,
                            const float *mass, float mconst, int64_t n,
                            double ld, double ld2, double boxsize, int nrep,
                            double fov, int npix,
                            float *xs, float *ys, float *ms, int64_t *sel_index)
+{
+    return orc_select_project_sn(x, y, z, mass, mconst, n, ld, ld2, boxsize, nrep, fov, npix, 0, xs, ys, ms, sel_index);
+}
+
+int64_t orc_select_project_sn(const float *x, const float *y, const float *z,
+                              const float *mass, float mconst, int64_t n,
+                              double ld, double ld2, double boxsize, int nrep,
+                              double fov, int npix, int snopt,
+                              float *xs, float *ys, float *ms, int64_t *sel_index)
 {
     double minDist = ld / boxsize * 1.e+3 / ORC_POS_U;
     double maxDist = ld2 / boxsize * 1.e+3 / ORC_POS_U;
@@ -158,7 +173,14 @@ int64_t orc_select_project(const float *x, const float *y, const float *z,
                     if (fabs(rai) <= lim && fabs(deci) <= lim) {
                         xs[k] = (float)(deci / fov + 0.5);
                         ys[k] = (float)(rai / fov + 0.5);
-                        ms[k] = m;
+                        if (snopt == 0) {
+                            ms[k] = m;
+                        } else { /* densitymaps.cpp:391-396 */
+                            if ((double)(rand() / (float)RAND_MAX) < 1. / pow(2, snopt))
+                                ms[k] = (float)(pow(2, snopt) * (double)m);
+                            else
+                                ms[k] = (float)0.;
+                        }
                         if (sel_index)
                             sel_index[k] = l;
                         k++;
@@ -216,12 +238,25 @@ typedef struct {
  * reference's out-param stays 0 because of the shadowing at :497; callers that
  * want reference-identical counts ignore nsel).  Returns 0, or 1 when the
  * negativity guard fires (maps then hold the state at the abort point).     */
+int orc_create_density_maps_sn(const orc_file *files, int ffmin, int ffmax, int npix, int hydro, int do_ngp, int snopt,
+                               double ld, double ld2, int nrepperp, double fov, int sgnx, int sgny, int sgnz, int face,
+                               double x0, double y0, double z0, float rcase, float *tot, float *toti, int64_t *nsel);
+
 int orc_create_density_maps(const orc_file *files, int ffmin, int ffmax,
                             int npix, int hydro, int do_ngp,
                             double ld, double ld2, int nrepperp, double fov,
                             int sgnx, int sgny, int sgnz, int face,
                             double x0, double y0, double z0, float rcase,
                             float *tot, float *toti /* [6][npix^2] */, int64_t *nsel)
+{
+    return orc_create_density_maps_sn(files, ffmin, ffmax, npix, hydro, do_ngp, 0, ld, ld2, nrepperp, fov, sgnx, sgny,
+                                      sgnz, face, x0, y0, z0, rcase, tot, toti, nsel);
+}
+
+/* same with InputParams.snopt (shot-noise thinning through libc rand(), densitymaps.cpp:387-397) */
+int orc_create_density_maps_sn(const orc_file *files, int ffmin, int ffmax, int npix, int hydro, int do_ngp, int snopt,
+                               double ld, double ld2, int nrepperp, double fov, int sgnx, int sgny, int sgnz, int face,
+                               double x0, double y0, double z0, float rcase, float *tot, float *toti, int64_t *nsel)
 {
     size_t np2 = (size_t)npix * (size_t)npix;
     memset(tot, 0, sizeof(float) * np2);
@@ -253,8 +288,8 @@ int orc_create_density_maps(const orc_file *files, int ffmin, int ffmax,
             float *xs = (float *)malloc(sizeof(float) * (size_t)n * rep * 3);
             float *ys = xs + (size_t)n * rep, *ms = ys + (size_t)n * rep;
             const float *pm = (hydro && f->massarr[t] == 0) ? f->mass[t] : NULL;
-            int64_t k = orc_select_project(x, y, z, pm, (float)f->massarr[t], n, ld, ld2, f->boxsize,
-                                           nrepperp, fov, npix, xs, ys, ms, NULL);
+            int64_t k = orc_select_project_sn(x, y, z, pm, (float)f->massarr[t], n, ld, ld2, f->boxsize,
+                                              nrepperp, fov, npix, snopt, xs, ys, ms, NULL);
             nsel[t] += k;
             if (k > 0)
                 orc_gridist_w(xs, ys, ms, k, npix, do_ngp, mapi + np2 * t);

@@ -76,6 +76,8 @@ struct slicer_handle_s {
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
     DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    DevBuf w_tcounts, w_tbase, w_urand;  // shot-noise thinning (snopt > 0)
+    std::vector<float> h_urand;
     uint64_t pend_particles = 0;  // particles behind the pending chunks (bounds their record count)
     DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
     // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
@@ -462,6 +464,38 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     Targets T;
     fill_targets(h, type, has_mass, T);
     LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
+    if (d.snopt > 0) {
+        // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device,
+        // draw on the host from the process-global stream (exactly what the reference consumes), deposit.
+        const uint64_t nchunks = (n + 63) / 64;
+        int rc;
+        if ((rc = ensure(h, h->w_tcounts, nchunks * 4)) || (rc = ensure(h, h->w_tbase, (nchunks + 1) * 8)))
+            return rc;
+        {
+            ProfScope ps(h, KN_DIRECT);
+            HIPCHK(h, launch_thin_count(d_pos, n, P, (unsigned *)h->w_tcounts.p, (unsigned long long *)h->w_tbase.p,
+                                        h->d_neg, h->stream));
+        }
+        unsigned long long nsel = 0;
+        HIPCHK(h, hipMemcpyAsync(&nsel, (unsigned long long *)h->w_tbase.p + nchunks, sizeof nsel,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->h_urand.resize(nsel);
+        for (unsigned long long k = 0; k < nsel; k++)
+            h->h_urand[k] = rand() / float(RAND_MAX);
+        if ((rc = ensure(h, h->w_urand, std::max<size_t>(nsel, 1) * 4)))
+            return rc;
+        if (nsel)
+            HIPCHK(h, hipMemcpyAsync(h->w_urand.p, h->h_urand.data(), nsel * 4, hipMemcpyHostToDevice, h->stream));
+        const double pw = std::pow(2, d.snopt);
+        {
+            ProfScope ps(h, KN_DIRECT);
+            HIPCHK(h, launch_thin_deposit(cfg, d_pos, d_mass, n, P, T, (const unsigned long long *)h->w_tbase.p,
+                                          (const float *)h->w_urand.p, 1. / pw, pw, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // h_urand is reused by the next chunk
+        return SLICER_OK;
+    }
     BinGeom G;
     bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G) &&
                   scatter_lds_bytes(G, has_mass) <= 160 * 1024 - 256;
@@ -538,6 +572,8 @@ int begin_type(slicer_handle h, int type, bool has_mass)
                         type);
         h->file_mode[type] = mode;
         h->file_mconst[type] = (float)h->file.massarr[type];
+        if (d.snopt > 0)  // kept entries carry (float)(pow(2, snopt) * m)   densitymaps.cpp:394
+            h->file_mconst[type] = (float)(std::pow(2, d.snopt) * (double)(float)h->file.massarr[type]);
     }
     return SLICER_OK;
 }
@@ -628,7 +664,8 @@ int slicer_destroy(slicer_handle h)
             release(pl.acc[t]);
         }
     }
-    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items})
+    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
+                      &h->w_tcounts, &h->w_tbase, &h->w_urand})
         release(*b);
     for (int i = 0; i < kMaxPending; i++) {
         release(h->w_sxy[i]);
@@ -671,11 +708,13 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
         return fail(h, SLICER_ERR_ARG, "unknown mass-assignment scheme %d", desc->mas);
     if (desc->accum < SLICER_ACC_F32 || desc->accum > SLICER_ACC_FIXED64)
         return fail(h, SLICER_ERR_ARG, "unknown accumulator %d", desc->accum);
-    if (desc->snopt != 0)
+    if (desc->snopt < 0 || desc->snopt > 30)
+        return fail(h, SLICER_ERR_ARG, "snopt = %d out of range 0..30", desc->snopt);
+    if (desc->snopt > 0 && desc->n_planes != 1)
         return fail(h, SLICER_ERR_UNSUPPORTED,
-                    "snopt = %d: shot-noise thinning draws from the process-global libc rand() stream in selection "
-                    "order (densitymaps.cpp:387-397); not supported on the device path",
-                    desc->snopt);
+                    "snopt = %d with %d planes in one pass: shot-noise thinning consumes the process-global libc rand() "
+                    "stream in selection order, plane by plane (densitymaps.cpp:387-397); use one plane per pass",
+                    desc->snopt, desc->n_planes);
     if (!(desc->fov_rad > 0))
         return fail(h, SLICER_ERR_ARG, "fov_rad must be > 0");
     for (int p = 0; p < desc->n_planes; p++)

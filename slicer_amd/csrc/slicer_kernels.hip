@@ -116,6 +116,142 @@ __global__ __launch_bounds__(256) void k_direct(const float *__restrict__ pos, c
         atomicOr(T.neg_flag, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shot-noise thinning (InputParams.snopt > 0, densitymaps.cpp:387-397): every selected entry, in the reference's
+// order (particle-major, then the (ni, nj) replicas), consumes one libc rand(); it keeps mass 2^snopt * m when
+// rand()/float(RAND_MAX) < 1/2^snopt and gets mass 0 otherwise.  The deviates are drawn on the host by the C ABI
+// (from the same process-global stream the reference uses), so the device needs each entry's ordinal:
+//   k_thin_count  : selected entries per 64-particle chunk (lane l of a chunk = particle 64*c + l)
+//   k_thin_scan   : exclusive prefix over chunks (single workgroup)
+//   k_thin_deposit: recomputes the selection, rank = base[chunk] + lanes before + replica index, then deposits
+// Two full projections per particle and global atomics: a faithful path for a rarely used option, not a fast one.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_prefix(unsigned v, unsigned &total)
+{
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = (unsigned)__shfl_up((int)x, d);
+        if ((int)(threadIdx.x & 63) >= d)
+            x += y;
+    }
+    total = (unsigned)__shfl((int)x, 63);
+    return x - v;
+}
+
+__global__ __launch_bounds__(256) void k_thin_count(const float *__restrict__ pos, uint64_t n, PassParams P,
+                                                    unsigned *__restrict__ counts, int *neg_flag)
+{
+    const uint64_t nchunks = (n + 63) / 64;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const unsigned lane = threadIdx.x & 63;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        unsigned v = 0;
+        if (i < n) {
+            float x, y, z;
+            transform(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], P, x, y, z);
+            if ((x < 0.0f) | (y < 0.0f) | (z < 0.0f))
+                atomicOr(neg_flag, 1);
+            if (z >= P.zlo[0] && z < P.zhi[0]) {
+                const int nr = P.nrep[0];
+                for (int ni = -nr; ni <= nr; ni++)
+                    for (int nj = -nr; nj <= nr; nj++) {
+                        float xs, ys;
+                        v += project(x, y, z, ni, nj, P, xs, ys) ? 1u : 0u;
+                    }
+            }
+        }
+        unsigned tot;
+        (void)lane_prefix(v, tot);
+        if (lane == 0)
+            counts[c] = tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_thin_scan(const unsigned *__restrict__ counts, unsigned long long *__restrict__ base,
+                                                    uint64_t nchunks)
+{
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (nchunks + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < nchunks ? lo + per : nchunks;
+    unsigned long long sum = 0;
+    for (uint64_t i = lo; i < hi; i++)
+        sum += counts[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = tid ? s_part[tid - 1] : 0;
+    for (uint64_t i = lo; i < hi; i++) {
+        base[i] = run;
+        run += counts[i];
+    }
+    if (tid == 1023)
+        base[nchunks] = s_part[1023];
+}
+
+template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+__global__ __launch_bounds__(256) void k_thin_deposit(const float *__restrict__ pos, const float *__restrict__ mass,
+                                                      uint64_t n, PassParams P, Targets T,
+                                                      const unsigned long long *__restrict__ base,
+                                                      const float *__restrict__ urand, double thr, double mfac)
+{
+    const uint64_t nchunks = (n + 63) / 64;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long nsel = 0;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        float x = 0, y = 0, z = 0;
+        bool inslab = false;
+        unsigned v = 0;
+        if (i < n) {
+            transform(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], P, x, y, z);
+            inslab = z >= P.zlo[0] && z < P.zhi[0];
+        }
+        const int nr = P.nrep[0];
+        if (inslab)
+            for (int ni = -nr; ni <= nr; ni++)
+                for (int nj = -nr; nj <= nr; nj++) {
+                    float xs, ys;
+                    v += project(x, y, z, ni, nj, P, xs, ys) ? 1u : 0u;
+                }
+        unsigned tot;
+        unsigned long long rank = base[c] + lane_prefix(v, tot);
+        nsel += v;
+        if (!inslab || v == 0)
+            continue;
+        float m0 = P.mconst;
+        if (HAS_MASS)
+            m0 = cap_mass(mass[i]);
+        for (int ni = -nr; ni <= nr; ni++)
+            for (int nj = -nr; nj <= nr; nj++) {
+                float xs, ys;
+                if (!project(x, y, z, ni, nj, P, xs, ys))
+                    continue;
+                const float u = urand[rank++];
+                if (!((double)u < thr))
+                    continue;  // ms = 0: contributes nothing (adds of +0.0f in the reference)
+                const float m = (float)(mfac * (double)m0);  // ms.push_back(pow(2, snopt) * num_float1)
+                deposit_global<MAS, ACC, POW2>(T.acc[0], xs, ys, m, __fsqrt_rn(m), P);
+            }
+    }
+    // selected-entry counter (all selected entries, kept or not, as totPartxyi counts them)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        nsel += (unsigned long long)__shfl_down((long long)nsel, d);
+    if (lane == 0 && nsel)
+        atomicAdd(T.nsel[0], nsel);
+}
+
 static inline int grid_for(uint64_t n, int block, int per_thread = 1)
 {
     uint64_t g = (n + (uint64_t)block * per_thread - 1) / ((uint64_t)block * per_thread);
@@ -365,6 +501,50 @@ hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams
     dim3 grid(grid_for(n, 256)), block(256);
     k_debug_project<<<grid, block, 0, s>>>(d_pos, n, P, d_xs, d_ys, d_plane, d_src, capacity, d_count, neg_flag);
     return hipGetLastError();
+}
+
+hipError_t launch_thin_count(const float *d_pos, uint64_t n, const PassParams &P, unsigned *counts,
+                             unsigned long long *base, int *neg_flag, hipStream_t s)
+{
+    const uint64_t nchunks = (n + 63) / 64;
+    k_thin_count<<<grid_for(n, 256), 256, 0, s>>>(d_pos, n, P, counts, neg_flag);
+    k_thin_scan<<<1, 1024, 0, s>>>(counts, base, nchunks);
+    return hipGetLastError();
+}
+
+template <int MAS, int ACC>
+static hipError_t launch_thin_2(bool pow2, bool has_mass, const float *pos, const float *mass, uint64_t n,
+                                const PassParams &P, const Targets &T, const unsigned long long *base,
+                                const float *urand, double thr, double mfac, hipStream_t s)
+{
+    dim3 grid(grid_for(n, 256)), block(256);
+#define THIN(P2_, HM_) k_thin_deposit<MAS, ACC, P2_, HM_><<<grid, block, 0, s>>>(pos, mass, n, P, T, base, urand, thr, mfac)
+    if (pow2) {
+        if (has_mass) THIN(true, true); else THIN(true, false);
+    } else {
+        if (has_mass) THIN(false, true); else THIN(false, false);
+    }
+#undef THIN
+    return hipGetLastError();
+}
+
+hipError_t launch_thin_deposit(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
+                               const PassParams &P, const Targets &T, const unsigned long long *base,
+                               const float *urand, double thr, double mfac, hipStream_t s)
+{
+    const bool pow2 = P.pow2 != 0;
+    if (cfg.mas == kNGP) {
+        if (cfg.acc == kCountU32)
+            return launch_thin_2<kNGP, kCountU32>(pow2, false, d_pos, d_mass, n, P, T, base, urand, thr, mfac, s);
+        return launch_thin_2<kNGP, kF32>(pow2, cfg.has_mass, d_pos, d_mass, n, P, T, base, urand, thr, mfac, s);
+    }
+    switch (cfg.acc) {
+    case kF32: return launch_thin_2<kTSC, kF32>(pow2, cfg.has_mass, d_pos, d_mass, n, P, T, base, urand, thr, mfac, s);
+    case kF64: return launch_thin_2<kTSC, kF64>(pow2, cfg.has_mass, d_pos, d_mass, n, P, T, base, urand, thr, mfac, s);
+    case kFixed64:
+        return launch_thin_2<kTSC, kFixed64>(pow2, cfg.has_mass, d_pos, d_mass, n, P, T, base, urand, thr, mfac, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace slicer

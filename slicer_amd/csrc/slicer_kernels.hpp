@@ -27,6 +27,13 @@ struct LaunchCfg {
 hipError_t launch_direct(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
                          const PassParams &P, const Targets &T, hipStream_t s);
 
+// shot-noise thinning path (snopt > 0): ordered selection ranks + host-drawn libc deviates (slicer_kernels.hip)
+hipError_t launch_thin_count(const float *d_pos, uint64_t n, const PassParams &P, unsigned *counts,
+                             unsigned long long *base, int *neg_flag, hipStream_t s);
+hipError_t launch_thin_deposit(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
+                               const PassParams &P, const Targets &T, const unsigned long long *base,
+                               const float *urand, double thr, double mfac, hipStream_t s);
+
 // tot = sum over types / accumulator -> f32 conversion, one plane
 struct FinalizeArgs {
     const void *acc[6];  // per-type accumulators (nullptr = type never appeared)

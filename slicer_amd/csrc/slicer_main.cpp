@@ -5,7 +5,7 @@
 //     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
 //   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
 //     partinplanes runs write their per-type files;                                      --reference-counts disables
-//   * SubFind / halo-catalogue mode (npix == 0) and snopt > 0 are not supported.
+//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass.
 #include <sys/stat.h>
 
 #include <cmath>
@@ -169,10 +169,8 @@ int main(int argc, char **argv)
         dump_plan(plan_path, p, lens, random, snapbox, fovradiants);
     if (plan_only)
         return 0;
-    if (p.snopt != 0) {
-        cerr << "snopt > 0 (shot-noise thinning through libc rand()) is not supported on the device path" << endl;
-        return 1;
-    }
+    if (p.snopt != 0)
+        single_plane = true;  // thinning consumes libc rand() plane by plane (densitymaps.cpp:387-397)
 
     slicer_handle h = nullptr;
     if (slicer_create(device, 1ull << 24, &h) != SLICER_OK) {
@@ -230,7 +228,7 @@ int main(int argc, char **argv)
         d.mas = mas;
         d.accum = accum;
         d.hydro = p.hydro;
-        d.snopt = 0;
+        d.snopt = p.snopt;
         d.want_type_maps = p.partinplanes ? 1 : 0;
         d.fov_rad = fovradiants;
         for (size_t k = 0; k < todo.size(); k++) {

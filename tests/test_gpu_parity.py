@@ -358,8 +358,8 @@ def test_empty_inputs_and_state_errors(S):
     assert tot.sum() == 0 and toti.sum() == 0 and cnt.sum() == 0
     with pytest.raises(slicer_amd.SlicerError):
         S.file_end()
-    with pytest.raises(slicer_amd.SlicerError):
-        S.plane_begin(16, 0.25, [3.0], [4.0], snopt=1)
+    with pytest.raises(slicer_amd.SlicerError):   # thinning consumes libc rand() plane by plane: one plane per pass
+        S.plane_begin(16, 0.25, [3.0, 3.5], [3.5, 4.0], snopt=1)
     with pytest.raises(slicer_amd.SlicerError):
         S.plane_begin(0, 0.25, [3.0], [4.0])
 
@@ -525,6 +525,52 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S):
         else:
             assert 0.999 * cnt16[1] * 0.25 <= total <= cnt16[1] * 0.25 * (1 + 1e-6)
         del big
+
+
+@pytest.mark.parametrize("snopt", [1, 3])
+def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
+    """InputParams.snopt > 0 (densitymaps.cpp:387-397): each selected entry draws one libc rand() in selection
+    order; kept entries weigh 2^snopt m, the rest 0.  Oracle and product share this process's libc stream, so after
+    srand(seed) both must consume the same deviates: NGP maps bit-exact, TSC within the usual bar, and the stream
+    must end in the same state."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    files, first = [], 0
+    for ff in range(2):
+        npart = [0, 40001 + ff, 3001, 0, 0, 0]
+        n = sum(npart)
+        files.append(dict(npart=npart, massarr=[0, 0.0123, 0.3, 0, 0, 0], boxsize=BOX, pos=synth.positions(first, n, BOX)))
+        first += n
+    npix, fov, ld, ld2 = 64, 0.25, 3.0, 4.0
+    for ngp in (True, False):
+        libc.srand(4242)
+        rc, ref_tot, ref_toti, nsel = oracle.create_density_maps(files, 0, 2, npix, False, ngp, ld, ld2, 0, fov,
+                                                                 RND["sgn"], RND["face"], RND["center"], RND["rcase"],
+                                                                 snopt=snopt)
+        after_ref = libc.rand()
+        libc.srand(4242)
+        S.plane_begin(npix, fov, [ld], [ld2], mas=slicer_amd.MAS_NGP if ngp else slicer_amd.MAS_TSC, snopt=snopt)
+        for f in files:
+            S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+            off = 0
+            for t in range(6):
+                if f["npart"][t]:
+                    S.deposit_host(t, f["pos"][off:off + f["npart"][t]])
+                off += f["npart"][t]
+            S.file_end()
+        tot, toti, cnt = S.plane_read(0)
+        assert libc.rand() == after_ref            # same number of deviates consumed
+        assert rc == 0 and np.array_equal(cnt, nsel)
+        kept = ref_toti[1].sum(dtype=np.float64) / (0.0123 * 2 ** snopt) / nsel[1]
+        # about one entry in 2^snopt survives (the map misses the few per cent of entries in the border ring)
+        assert 0.8 * 2.0 ** -snopt < kept < 1.05 * 2.0 ** -snopt
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+            assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
+        else:
+            assert np.array_equal(tot == 0, ref_tot == 0)
+            d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+            assert np.all(d <= 3e-6 * ref_tot)
 
 
 def test_rccl_plane_reduce_single_rank(S):
