@@ -323,12 +323,15 @@ int prepare_type(slicer_handle h, int type, bool has_mass)
             h->fixed_exp_set[type] = true;
         }
         for (int p = 0; p < d.n_planes; p++) {
-            int rc = ensure(h, h->planes[p].toti[type], n4);
-            if (rc)
-                return rc;
-            rc = zero_async(h, h->planes[p].toti[type].p, n4);
-            if (rc)
-                return rc;
+            int rc = SLICER_OK;
+            if (!ngp || d.want_type_maps) {  // NGP without per-type outputs only needs the count scratch
+                rc = ensure(h, h->planes[p].toti[type], n4);
+                if (rc)
+                    return rc;
+                rc = zero_async(h, h->planes[p].toti[type].p, n4);
+                if (rc)
+                    return rc;
+            }
             if (ngp || kind != kF32) {
                 size_t b = h->npix2 * (ngp ? 4 : acc_elem_size(kind));
                 rc = ensure(h, h->planes[p].acc[type], b);
@@ -633,7 +636,8 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
     if (!h)
         return fail(nullptr, SLICER_ERR_NOMEM, "out of host memory");
     h->device = device;
-    h->max_chunk = max_chunk ? max_chunk : (1ull << 24);
+    // record cursors are 32-bit: one kernel pass carries at most 2^30 particles
+    h->max_chunk = max_chunk ? std::min<uint64_t>(max_chunk, 1ull << 30) : (1ull << 24);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->own) != hipSuccess ||
         hipMalloc((void **)&h->d_counts, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6) != hipSuccess ||
         hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess) {
@@ -877,7 +881,7 @@ int slicer_file_end(slicer_handle h)
                     A.mode[t] = h->file_mode[t];
                     A.mconst[t] = h->file_mconst[t];
                     A.scratch[t] = h->file_mode[t] ? h->planes[p].acc[t].p : nullptr;
-                    A.toti[t] = h->file_mode[t] ? (float *)h->planes[p].toti[t].p : nullptr;
+                    A.toti[t] = (h->file_mode[t] && h->desc.want_type_maps) ? (float *)h->planes[p].toti[t].p : nullptr;
                 }
                 A.tot = (float *)h->planes[p].tot.p;
                 A.npix2 = h->npix2;
@@ -953,7 +957,7 @@ int slicer_plane_device_maps(slicer_handle h, int plane, float **d_tot, float **
         *d_tot = (float *)h->planes[plane].tot.p;
     if (d_toti)
         for (int t = 0; t < 6; t++)
-            d_toti[t] = h->type_seen[t] ? (float *)h->planes[plane].toti[t].p : nullptr;
+            d_toti[t] = (h->type_seen[t] && h->desc.want_type_maps) ? (float *)h->planes[plane].toti[t].p : nullptr;
     return SLICER_OK;
 }
 
@@ -1019,7 +1023,7 @@ int slicer_plane_read(slicer_handle h, int plane, float *tot, float *toti, int64
         HIPCHK(h, hipMemcpy(tot, h->planes[plane].tot.p, n4, hipMemcpyDeviceToHost));
     if (toti) {
         for (int t = 0; t < 6; t++) {
-            if (h->type_seen[t])
+            if (h->type_seen[t] && h->desc.want_type_maps)
                 HIPCHK(h, hipMemcpy(toti + h->npix2 * t, h->planes[plane].toti[t].p, n4, hipMemcpyDeviceToHost));
             else
                 memset(toti + h->npix2 * t, 0, n4);
