@@ -123,15 +123,15 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
     float4 *q4 = reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) + (size_t)wave * kWaveQ;
     float *qm = reinterpret_cast<float *>(reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) +
                                           (size_t)kWaves * kWaveQ) + (size_t)wave * kWaveQ;  // only with HAS_MASS
-    __shared__ unsigned s_out[kMaxPlanes], s_cnt[kMaxPlanes];
+    __shared__ unsigned s_out[kMaxUnits], s_cnt[kMaxPlanes];
     __shared__ int s_neg;
 
     for (int i = tid; i < hist_words; i += kK1Block)
         s_hist[i] = 0;
-    if (tid < kMaxPlanes) {
+    if (tid < kMaxPlanes)
         s_cnt[tid] = 0;
+    if (tid < kMaxUnits)
         s_out[tid] = 0;
-    }
     if (tid == 0)
         s_neg = 0;
     __syncthreads();
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
             const unsigned e = top - take + lane;
             bool emit = false, valid = false;
             float xs = 0.f, ys = 0.f, m = 0.f;
-            unsigned bin = 0;
+            unsigned bin = 0, unit = 0, tile_in_unit = 0;
             int plane = 0;
             if (lane < take) {
                 const float4 ent = q4[e];
@@ -214,36 +214,45 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
                         gx = gx < 0 ? 0 : (gx >= nn ? nn - 1 : gx);
                         gy = gy < 0 ? 0 : (gy >= nn ? nn - 1 : gy);
                     }
-                    bin = (unsigned)plane * (unsigned)G.tiles_per_plane +
-                          (unsigned)(gy >> G.th_log2) * (unsigned)G.ntx + (unsigned)(gx >> G.tw_log2);
+                    const unsigned ty = (unsigned)(gy >> G.th_log2), tx = (unsigned)(gx >> G.tw_log2);
+                    unsigned band = 0, trow = ty;
+                    if (G.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
+                        band = ty / (unsigned)G.rows_per_unit;
+                        trow = ty - band * (unsigned)G.rows_per_unit;
+                    }
+                    unit = (unsigned)plane * (unsigned)G.units_per_plane + band;
+                    tile_in_unit = trow * (unsigned)G.ntx + tx;
+                    bin = unit * (unsigned)G.tiles_per_unit + tile_in_unit;
                     if (HAS_MASS)
                         m = qm[e];
                 }
             }
             top -= take;
-            // Records go to the compact region of (plane, workgroup): [ (plane*gridDim.x + blockIdx.x) * batch, ... ).
-            // One reservation per wave and plane (ballot + popcount, a single returning LDS add by the leader).
+            for (int p = 0; p < P.n_planes; p++) {  // selected-entry counters: one LDS add per wave and plane
+                const unsigned c = (unsigned)__popcll(__ballot(valid && plane == p));
+                if (c && lane == 0)
+                    atomicAdd(&s_cnt[p], c);
+            }
+            // Records go to the compact region of (unit, workgroup): [ (unit*gridDim.x + blockIdx.x) * batch, ... ).
+            // One reservation per wave and distinct unit (a single returning LDS add by that unit's first lane).
             unsigned o = 0;
-            for (int p = 0; p < P.n_planes; p++) {
-                const unsigned long long mv = __ballot(valid && plane == p);
-                if (mv == 0ull)
-                    continue;
-                const unsigned long long me = MAS == kNGP ? __ballot(emit && plane == p) : mv;
-                const int leader = __ffsll((long long)mv) - 1;
+            unsigned long long todo = __ballot(emit);
+            while (todo != 0ull) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const unsigned u = (unsigned)__shfl((int)unit, leader);
+                const unsigned long long me = __ballot(emit && unit == u);
                 unsigned base = 0;
-                if ((int)lane == leader) {
-                    atomicAdd(&s_cnt[p], (unsigned)__popcll(mv));
-                    if (me != 0ull)
-                        base = atomicAdd(&s_out[p], (unsigned)__popcll(me));
-                }
+                if ((int)lane == leader)
+                    base = atomicAdd(&s_out[u], (unsigned)__popcll(me));
                 base = (unsigned)__shfl((int)base, leader);
-                if (emit && plane == p)
+                if (emit && unit == u)
                     o = base + (unsigned)__popcll(me & ((1ull << lane) - 1ull));
+                todo &= ~me;
             }
             if (emit) {
-                const uint64_t dst = ((uint64_t)plane * gridDim.x + blockIdx.x) * (uint64_t)G.batch + o;
+                const uint64_t dst = ((uint64_t)unit * gridDim.x + blockIdx.x) * (uint64_t)G.batch + o;
                 cxy[dst] = make_float2(xs, ys);
-                cbin[dst] = (unsigned short)(bin - (unsigned)plane * (unsigned)G.tiles_per_plane);  // tile in plane
+                cbin[dst] = (unsigned short)tile_in_unit;
                 if (HAS_MASS)
                     cm[dst] = m;
                 atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
@@ -274,8 +283,8 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
     unsigned *row = hist16 + (size_t)blockIdx.x * hist_words;  // u16 [nbins] packed, row stride hist_words words
     for (int i = tid; i < hist_words; i += kK1Block)
         row[i] = s_hist[i];
-    if (tid < P.n_planes)
-        bcount[(size_t)tid * gridDim.x + blockIdx.x] = s_out[tid];  // [plane][workgroup]
+    if (tid < G.n_units)
+        bcount[(size_t)tid * gridDim.x + blockIdx.x] = s_out[tid];  // [unit][workgroup]
     if (tid == 0 && s_neg)
         atomicOr(T.neg_flag, 1);
     if (tid < P.n_planes && s_cnt[tid])
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__
 // ---------------------------------------------------------------------------------------------
 // K3: scatter records into their bin runs
 // ---------------------------------------------------------------------------------------------
-// One workgroup per (plane, K1 workgroup) unit.  Its records are counting-sorted by tile in LDS (sub-batches of
+// One workgroup per (unit, K1 workgroup) pair (a unit is a plane, or a band of tile rows of a plane on large maps).  Its records are counting-sorted by tile in LDS (sub-batches of
 // kSortBatch records), so that the records of one (unit, tile) run are stored by adjacent lanes: a plain
 // scatter issues one 32-byte sector write per 8-byte record (measured write amplification 4.2x), runs of
 // 3-8 records cut that to 1-2 sectors per run.
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__rest
                                                             float *__restrict__ sm)
 {
     extern __shared__ unsigned smem_sc[];
-    const int tpp = G.tiles_per_plane;
+    const int tpp = G.tiles_per_unit;
     const int tw = (tpp + 1) >> 1;    // words of a packed u16 table
     unsigned *cnt = smem_sc;          // [tpp] u16 x2 per word: records of the sub-batch per tile (<= kSortBatch)
     unsigned *pos0 = cnt + tw;        // [tpp] u16 x2 per word: running LDS position (ends at start + cnt)
@@ -398,11 +407,11 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__rest
     __shared__ unsigned s_wave[kSortBlock / 64];
 
     const int tid = threadIdx.x;
-    // unit -> (plane, K1 workgroup); XCD-aware order inside the plane (speed only, see k_project_bin notes)
-    const int per_plane = 8 * ((nblocks + 7) / 8);
-    const int plane = blockIdx.x / per_plane;
-    const int u = blockIdx.x % per_plane;
-    const int per_xcd = per_plane / 8;
+    // workgroup -> (unit, K1 workgroup); XCD-aware order inside the unit (speed only, see k_project_bin notes)
+    const int per_unit = 8 * ((nblocks + 7) / 8);
+    const int plane = blockIdx.x / per_unit;  // the unit index (a whole plane unless the map is large)
+    const int u = blockIdx.x % per_unit;
+    const int per_xcd = per_unit / 8;
     const int lb = (u & 7) * per_xcd + (u >> 3);
     if (lb >= nblocks)
         return;
@@ -582,10 +591,12 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         return;
     const uint2 item = I.items[blockIdx.x];
     const unsigned bin = item.x, part = item.y, nparts = I.nparts[bin];
-    const int plane = bin / G.tiles_per_plane;
-    const int t = bin % G.tiles_per_plane;
+    const int unit = bin / G.tiles_per_unit;
+    const int t = bin % G.tiles_per_unit;
+    const int plane = unit / G.units_per_plane;
+    const int band = unit % G.units_per_plane;
     const int x0 = (t % G.ntx) << G.tw_log2;
-    const int y0 = (t / G.ntx) << G.th_log2;
+    const int y0 = (band * G.rows_per_unit + t / G.ntx) << G.th_log2;
     const int W = (1 << G.tw_log2) + 2, H = (1 << G.th_log2) + 2;
     const int cells = W * H;
     const int tid = threadIdx.x;
@@ -691,6 +702,14 @@ static hipError_t launch_k1(bool vec, const float *pos, const float *mass, uint6
 {
     const int nb = (int)((n + G.batch - 1) / G.batch);
     const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
+    if (lds > 48 * 1024) {  // large maps: up to 64 KiB of histogram + 40 KiB of wave stacks
+        hipError_t e = hipFuncSetAttribute(
+            vec ? reinterpret_cast<const void *>(k_project_bin<MAS, POW2, HAS_MASS, true>)
+                : reinterpret_cast<const void *>(k_project_bin<MAS, POW2, HAS_MASS, false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
     if (vec)
         k_project_bin<MAS, POW2, HAS_MASS, true><<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm,
                                                                          W.hist16, W.bcount, T);
@@ -728,15 +747,14 @@ hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W,
 
 size_t scatter_lds_bytes(const BinGeom &G, bool has_mass)
 {
-    const size_t tpp = (size_t)G.tiles_per_plane, tw = (tpp + 1) >> 1;
+    const size_t tpp = (size_t)G.tiles_per_unit, tw = (tpp + 1) >> 1;
     return 4 * (2 * tw + tpp + (tpp & 1)) + (size_t)kSortBatch * (8 + 2 + (has_mass ? 4 : 0));
 }
 
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
-                              hipStream_t s)
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
 {
     const size_t lds = scatter_lds_bytes(G, has_mass);
-    const int grid = n_planes * 8 * ((nblocks + 7) / 8);
+    const int grid = G.n_units * 8 * ((nblocks + 7) / 8);
     const unsigned short *cb = reinterpret_cast<const unsigned short *>(W.cbin);
     hipError_t e;
     if (has_mass) {

@@ -367,7 +367,8 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
 }
 
 constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
-constexpr int kMaxBins = 8192;    // LDS histogram / cursor table: 32 KiB
+constexpr int kMaxBins = 32768;   // all (unit, tile) bins of a pass: K1's packed u16 histogram is <= 64 KiB of LDS
+constexpr int kUnitBins = 8192;   // up to this many bins the units are whole planes
 
 // Tile geometry of the binned path.  Tiles are powers of two so that pixel -> tile is a shift.  4-byte
 // LDS cells (NGP counts): up to 128 x 128 (+halo = 67.6 KiB of LDS, two workgroups per CU); 8-byte: 64 x 128.
@@ -400,9 +401,20 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     }
     G.ntx = (d.npix + (1 << G.tw_log2) - 1) >> G.tw_log2;
     G.nty = (d.npix + (1 << G.th_log2) - 1) >> G.th_log2;
-    G.tiles_per_plane = G.ntx * G.nty;
-    long nb = (long)G.tiles_per_plane * d.n_planes;
-    if (nb > kMaxBins)
+    // units: whole planes while everything fits kUnitBins tiles, otherwise bands of tile rows (large maps)
+    static const int env_rows = getenv("SLICER_UNIT_ROWS") ? atoi(getenv("SLICER_UNIT_ROWS")) : 0;  // tests
+    const long tiles_plane = (long)G.ntx * G.nty;
+    if (tiles_plane * d.n_planes <= kUnitBins && !env_rows) {
+        G.units_per_plane = 1;
+        G.rows_per_unit = G.nty;
+    } else {
+        G.rows_per_unit = env_rows ? std::min(env_rows, G.nty) : std::max(1, 2048 / G.ntx);
+        G.units_per_plane = (G.nty + G.rows_per_unit - 1) / G.rows_per_unit;
+    }
+    G.tiles_per_unit = G.rows_per_unit * G.ntx;
+    G.n_units = d.n_planes * G.units_per_plane;
+    const long nb = (long)G.n_units * G.tiles_per_unit;
+    if (G.n_units > kMaxUnits || G.tiles_per_unit > 8192 || nb > kMaxBins)
         return false;
     G.nbins = (int)nb;
     // tuning overrides (SLICER_TILE_LOG2 / SLICER_TILE_H_LOG2 / SLICER_BIN_BATCH): the batch must be a multiple of
@@ -416,12 +428,12 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
 int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, const BinGeom &G, BinWorkspace &W)
 {
     const uint64_t nb = (n + G.batch - 1) / G.batch;
-    const uint64_t region = (uint64_t)h->desc.n_planes * nb * G.batch;  // compact records: [plane][workgroup][batch]
+    const uint64_t region = (uint64_t)G.n_units * nb * G.batch;  // compact records: [unit][workgroup][batch]
     int rc;
     if ((rc = ensure(h, h->w_cxy, region * 8)) || (rc = ensure(h, h->w_cbin, region * 2)) ||
         (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
         (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
-        (rc = ensure(h, h->w_bcount, nb * SLICER_MAX_PLANES * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
+        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
         (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
     if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], n * 4))))
@@ -529,7 +541,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, d.n_planes, G, W, h->stream));
+        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, G, W, h->stream));
     }
     if (slot == 0) {
         h->pend_key = key;

@@ -68,14 +68,20 @@ hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams
 struct BinGeom {
     int tw_log2, th_log2;  // tile width / height in pixels (powers of two)
     int ntx, nty;          // tiles per map row / column
-    int tiles_per_plane;
-    int nbins;             // n_planes * tiles_per_plane
+    // A *unit* is what one scatter workgroup group and one compact region serve: a whole plane while a plane has
+    // <= 8192 tiles in total with the others, otherwise a band of rows_per_unit tile rows of one plane (large maps).
+    int tiles_per_unit;    // rows_per_unit * ntx
+    int units_per_plane;   // 1, or ceil(nty / rows_per_unit)
+    int rows_per_unit;     // tile rows per unit
+    int n_units;           // n_planes * units_per_plane (<= kMaxUnits)
+    int nbins;             // n_units * tiles_per_unit; bin = unit * tiles_per_unit + tile_in_unit
     int batch;             // particles per K1 workgroup (= size of its region in the compact buffer)
 };
+constexpr int kMaxUnits = 32;
 
 struct BinWorkspace {
-    float2 *cxy;       // [n_planes][nblocks][batch] compact (xs, ys) of (plane, K1 workgroup), bcount[plane][b] valid
-    unsigned *cbin;    // [max_chunk] u16 bin of each compact record (nbins <= 8192)
+    float2 *cxy;       // [n_units][nblocks][batch] compact (xs, ys) of (unit, K1 workgroup), bcount[unit][b] valid
+    unsigned *cbin;    // same shape, u16 tile-in-unit of each compact record
     float *cm;         // [max_chunk] per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
     float *sm;         // [max_chunk] or nullptr
@@ -83,7 +89,7 @@ struct BinWorkspace {
     unsigned *hist;    // [nblocks][nbins] exclusive prefix over workgroups (write cursors)
     unsigned *total;   // [nbins]
     unsigned *base;    // [nbins + 1] start of every bin's run in sxy
-    unsigned *bcount;  // [n_planes][nblocks]
+    unsigned *bcount;  // [n_units][nblocks]
 };
 
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
@@ -93,7 +99,7 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
                               const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
                               hipStream_t s);
 hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W,
                               hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).

@@ -573,6 +573,21 @@ def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
             assert np.all(d <= 3e-6 * ref_tot)
 
 
+@pytest.mark.parametrize("rows", [1, 3])
+def test_band_units_layout_on_small_maps(rows):
+    """Large maps split every plane into units of a few tile rows (more than 8192 (plane, tile) bins).  The
+    SLICER_UNIT_ROWS override forces that layout on 512^2 / 1000^2 maps in a fresh process, where NGP can be
+    compared bit for bit with the oracle and fixed-point TSC with the fused kernel."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SLICER_UNIT_ROWS=str(rows))
+    r = subprocess.run([sys.executable, os.path.join(here, "unit_rows_probe.py")], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0 and "unit-rows probe ok" in r.stdout, r.stderr[-1500:]
+
+
 def test_rccl_plane_reduce_single_rank(S):
     """slicer_amd_rccl.h on a one-rank communicator: the sum over ranks is the identity; exercises the
     ncclReduce call sequence (maps + counters) on the handle's stream.  Multi-rank runs need >1 GPU."""
