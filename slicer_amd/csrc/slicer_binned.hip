@@ -26,7 +26,10 @@ namespace slicer {
 namespace {
 
 constexpr int kK1Block = 512;   // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
-constexpr int kPerThread = 4;
+#ifndef SLICER_K1_PER_THREAD
+#define SLICER_K1_PER_THREAD 4
+#endif
+constexpr int kPerThread = SLICER_K1_PER_THREAD;  // particles per lane and round (4: three dwordx4 loads)
 constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 workgroup
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
@@ -79,13 +82,17 @@ __device__ __forceinline__ void load_round(const float *__restrict__ pos, const 
                                            int nvalid, float (&rx)[kPerThread], float (&ry)[kPerThread],
                                            float (&rz)[kPerThread], float (&rm)[kPerThread])
 {
+    static_assert(kPerThread % 4 == 0, "four particles = three dwordx4 loads");
     if (VEC && nvalid == kPerThread) {
         const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
-        const float4 a = p4[0], b = p4[1], c = p4[2];
-        rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
-        rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
-        rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
-        rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
+#pragma unroll
+        for (int g = 0; g < kPerThread / 4; g++) {
+            const float4 a = p4[3 * g], b = p4[3 * g + 1], c = p4[3 * g + 2];
+            rx[4 * g + 0] = a.x; ry[4 * g + 0] = a.y; rz[4 * g + 0] = a.z;
+            rx[4 * g + 1] = a.w; ry[4 * g + 1] = b.x; rz[4 * g + 1] = b.y;
+            rx[4 * g + 2] = b.z; ry[4 * g + 2] = b.w; rz[4 * g + 2] = c.x;
+            rx[4 * g + 3] = c.y; ry[4 * g + 3] = c.z; rz[4 * g + 3] = c.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
