@@ -927,6 +927,11 @@ int slicer_plane_finalize(slicer_handle h)
             FinalizeArgs A;
             memset(&A, 0, sizeof A);
             bool any = false;
+            if (!d.want_type_maps && kind == kF32 && h->shared_seen) {
+                // the shared f32 accumulator already is the all-types map: hand the buffer over instead of copying
+                std::swap(h->planes[p].tot, h->planes[p].acc_shared);
+                continue;
+            }
             if (!d.want_type_maps) {
                 A.acc_shared = h->shared_seen ? h->planes[p].acc_shared.p : nullptr;
                 A.inv_scale_shared = std::ldexp(1.0, -h->fixed_exp_shared);
