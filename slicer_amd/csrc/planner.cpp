@@ -242,132 +242,112 @@ int getSnap(vector<double> &zsnap, const NaturalCubicSpline &GetDl, double dlens
 }
 
 // ---------------------------------------------------------------- densitymaps.cpp:46-156
+// Plane grid: slabs of (box / numOfLensPerSnap) piled from the observer until the source distance p.Ds is passed.
+// For every slab the snapshot is the one whose redshift is nearest to the redshift of the slab; switching to a
+// snapshot with a different box size is only allowed at a replication boundary (every numOfLensPerSnap slabs).
 int buildPlanes(InputParams &p, Lens &lens, vector<double> &snapred, vector<string> &snappath, vector<double> &snapbox,
                 const NaturalCubicSpline &GetDl, const NaturalCubicSpline &GetZl, int numOfLensPerSnap, int myid)
 {
-    size_t nsnaps = snapred.size();
-    int pos = 0;
-    int nrepi = 0;
-    int nrep = 0;
-    double zdbut, ldbut = 0.0;
+    const size_t nsnaps = snapred.size();
+    auto slab_depth = [&](size_t snap) { return snapbox[snap] / (1e3 / kPosU) / numOfLensPerSnap; };
+
+    int in_use = 0;          // snapshot the previous slab was cut from
+    int slabs_in_run = 0;    // slabs since the snapshot last changed
+    int n_slabs = 0;
+    double far_edge = 0.0;   // comoving distance of the last slab's far edge (Mpc/h)
     do {
-        nrep++;
-        nrepi++;
-        double ztest = 9999;
-        int pos_temp = pos;
-        for (size_t i = pos_temp; i < nsnaps; i++) {
-            double dtest = ldbut + snapbox[i] / (1e3 / kPosU) / numOfLensPerSnap;
-            int itest = getSnap(snapred, GetDl, dtest);
-            if (itest == -1) {
+        n_slabs++;
+        slabs_in_run++;
+        const bool at_replication_boundary = n_slabs == 1 || (n_slabs - 1) % numOfLensPerSnap == 0;
+
+        // trial: which snapshot suits a slab ending at far_edge + its own depth?
+        double best_dz = 9999;
+        int choice = in_use;
+        for (size_t cand = (size_t)in_use; cand < nsnaps; cand++) {
+            const double trial_edge = far_edge + slab_depth(cand);
+            const int nearest = getSnap(snapred, GetDl, trial_edge);
+            if (nearest == -1) {
                 cerr << "snapred is an empty array!" << endl;
                 cerr << "Check your snapshot list file." << endl;
                 return 1;
             }
-            if ((size_t)itest >= snapred.size()) {
+            if ((size_t)nearest >= snapred.size()) {
                 cerr << "getSnap returned an index outside the range! " << endl;
                 return 1;
             }
-            double dz = fabs(snapred[itest] - GetZl.eval(dtest));
-            if (dz < ztest) {
-                if (nrep == 1 || (!bool((nrep - 1) % numOfLensPerSnap) || snapbox[itest] == snapbox[pos])) {
-                    pos_temp = itest;
-                    ztest = dz;
-                }
+            const double dz = fabs(snapred[nearest] - GetZl.eval(trial_edge));
+            const bool may_switch = at_replication_boundary || snapbox[nearest] == snapbox[in_use];
+            if (dz < best_dz && may_switch) {
+                choice = nearest;
+                best_dz = dz;
             }
         }
-        ldbut += snapbox[pos_temp] / (1e3 / kPosU) / numOfLensPerSnap;
-        zdbut = GetZl.eval(ldbut);
-        double dlens = ldbut - 0.5 * snapbox[pos_temp] / (1e3 / kPosU) / numOfLensPerSnap;
-        double zlens = GetZl.eval(dlens);
-        pos_temp = getSnap(snapred, GetDl, dlens);
+        const double depth = slab_depth((size_t)choice);
+        far_edge += depth;
+        const double centre = far_edge - 0.5 * depth;
+        const double z_centre = GetZl.eval(centre);
+        const int snap = getSnap(snapred, GetDl, centre);  // the slab is finally cut from the snapshot nearest its centre
         if (myid == 0)
-            cout << " simulation snapshots = " << ldbut << "  " << zdbut << "  " << nrep << " from snap "
-                 << snappath[pos_temp] << "  " << zlens << endl;
-        lens.ld.push_back(ldbut - snapbox[pos_temp] / (1e3 / kPosU) / numOfLensPerSnap);
-        lens.ld2.push_back(ldbut);
-        lens.zfromsnap.push_back(snapred[pos_temp]);
-        if (nrep != 1 && pos_temp != pos) {
-            for (int i = 0; i < nrepi - 1; i++)
-                lens.replication.push_back(nrep - 1);
-            nrepi = 1;
+            cout << " simulation snapshots = " << far_edge << "  " << GetZl.eval(far_edge) << "  " << n_slabs
+                 << " from snap " << snappath[snap] << "  " << z_centre << endl;
+        lens.ld.push_back(far_edge - slab_depth((size_t)snap));
+        lens.ld2.push_back(far_edge);
+        lens.zfromsnap.push_back(snapred[snap]);
+        if (n_slabs != 1 && snap != in_use) {  // close the run of the previous snapshot
+            lens.replication.insert(lens.replication.end(), (size_t)(slabs_in_run - 1), n_slabs - 1);
+            slabs_in_run = 1;
         }
-        pos = pos_temp;
-        lens.zsimlens.push_back(zlens);
-        lens.fromsnap.push_back(snappath[pos]);
-        lens.fromsnapi.push_back(pos);
-        if (nrep == 1)
-            lens.randomize.push_back(1);
-        else
-            lens.randomize.push_back(!((nrep - 1) % numOfLensPerSnap));
-    } while (ldbut < p.Ds);
+        in_use = snap;
+        lens.zsimlens.push_back(z_centre);
+        lens.fromsnap.push_back(snappath[in_use]);
+        lens.fromsnapi.push_back(in_use);
+        lens.randomize.push_back(at_replication_boundary);
+    } while (far_edge < p.Ds);
+    // the last run (the reference pushes one entry more than it has slabs; .back() is what is read)
+    lens.replication.insert(lens.replication.end(), (size_t)(slabs_in_run + 1), n_slabs);
 
-    for (int i = 0; i < nrepi + 1; i++)
-        lens.replication.push_back(nrep);  // last plane replications
     if (myid == 0) {
         cout << " Comoving Distance of the last plane " << p.Ds << endl;
         cout << " nsnaps = " << nsnaps << "\n" << endl;
     }
     std::ofstream planelist;
-    string planes_list = p.directory + "planes_list_" + p.suffix + ".txt";
     if (myid == 0)
-        planelist.open(planes_list.c_str());
+        planelist.open((p.directory + "planes_list_" + p.suffix + ".txt").c_str());
     for (size_t i = 0; i < lens.fromsnap.size(); i++) {
         if (myid == 0) {
             cout << lens.zsimlens[i] << " planes = " << lens.ld[i] << "  " << lens.ld2[i] << "  " << lens.replication[i]
                  << " from snap " << lens.fromsnap[i] << endl;
+            // columns read back by Lens/kslicer.py: index, z, Dl low, Dl up, replication, snapshot, z snapshot, randomize
             planelist << i << "   " << lens.zsimlens[i] << "   " << lens.ld[i] << "   " << lens.ld2[i] << "   "
                       << lens.replication[i] << "   " << lens.fromsnap[i] << "   " << lens.zfromsnap[i] << "  "
                       << lens.randomize[i] << endl;
         }
         lens.pll.push_back((int)i);
     }
-    if (myid == 0)
-        planelist.close();
     lens.nplanes = lens.replication.back();
     return 0;
 }
 
 // ---------------------------------------------------------------- densitymaps.cpp:166-248
+// One Random entry per plane; drawn afresh at replication boundaries (lens.randomize), copied otherwise.  The
+// three seeds are re-armed per replication g = i / numOfLensPerSnap with strides 13, 5 and 8, and every draw is
+// rand()/float(RAND_MAX): the same libc calls in the same order as the reference, hence the same plan.
 void randomizeBox(Random &random, Lens &lens, InputParams &p, int numOfLensPerSnap, int myid, bool fixed_plc_vertex)
 {
-    size_t nrandom = lens.replication.back();
-    random.x0.resize(nrandom);
-    random.y0.resize(nrandom);
-    random.z0.resize(nrandom);
-    random.sgnX.resize(nrandom);
-    random.sgnY.resize(nrandom);
-    random.sgnZ.resize(nrandom);
-    random.face.resize(nrandom);
-    for (size_t i = 0; i < nrandom; i++) {
-        if (lens.randomize[i]) {
-            srand(p.seedcenter + i / numOfLensPerSnap * 13);
-            if (!fixed_plc_vertex) {
-                random.x0[i] = rand() / float(RAND_MAX);
-                random.y0[i] = rand() / float(RAND_MAX);
-                random.z0[i] = rand() / float(RAND_MAX);
-            } else {  // -DUSE_FIXED_PLC_VERTEX
-                random.x0[i] = 0.0;
-                random.y0[i] = 0.0;
-                random.z0[i] = 0.5;
-            }
-            random.face[i] = 7;
-            srand(p.seedface + i / numOfLensPerSnap * 5);
-            while (random.face[i] > 6 || random.face[i] < 1)
-                random.face[i] = int(1 + rand() / float(RAND_MAX) * 5. + 0.5);
-            random.sgnX[i] = 2;
-            srand(p.seedsign + i / numOfLensPerSnap * 8);
-            while (random.sgnX[i] > 1 || random.sgnX[i] < 0)
-                random.sgnX[i] = int(rand() / float(RAND_MAX) + 0.5);
-            random.sgnY[i] = 2;
-            while (random.sgnY[i] > 1 || random.sgnY[i] < 0)
-                random.sgnY[i] = int(rand() / float(RAND_MAX) + 0.5);
-            random.sgnZ[i] = 2;
-            while (random.sgnZ[i] > 1 || random.sgnZ[i] < 0)
-                random.sgnZ[i] = int(rand() / float(RAND_MAX) + 0.5);
-            if (random.sgnX[i] == 0) random.sgnX[i] = -1;
-            if (random.sgnY[i] == 0) random.sgnY[i] = -1;
-            if (random.sgnZ[i] == 0) random.sgnZ[i] = -1;
-        } else {
+    const size_t n = (size_t)lens.replication.back();
+    for (auto *v : {&random.x0, &random.y0, &random.z0})
+        v->resize(n);
+    for (auto *v : {&random.sgnX, &random.sgnY, &random.sgnZ, &random.face})
+        v->resize(n);
+    auto uniform01 = []() { return rand() / float(RAND_MAX); };
+    auto draw_sign = [&]() {
+        int s = 2;
+        while (s > 1 || s < 0)
+            s = int(uniform01() + 0.5);
+        return s == 0 ? -1 : s;
+    };
+    for (size_t i = 0; i < n; i++) {
+        if (!lens.randomize[i]) {  // same box replication as the previous plane
             random.x0[i] = random.x0[i - 1];
             random.y0[i] = random.y0[i - 1];
             random.z0[i] = random.z0[i - 1];
@@ -375,6 +355,27 @@ void randomizeBox(Random &random, Lens &lens, InputParams &p, int numOfLensPerSn
             random.sgnX[i] = random.sgnX[i - 1];
             random.sgnY[i] = random.sgnY[i - 1];
             random.sgnZ[i] = random.sgnZ[i - 1];
+        } else {
+            const size_t g = i / numOfLensPerSnap;
+            srand(p.seedcenter + g * 13);
+            if (fixed_plc_vertex) {  // -DUSE_FIXED_PLC_VERTEX: observer on the box axis
+                random.x0[i] = 0.0;
+                random.y0[i] = 0.0;
+                random.z0[i] = 0.5;
+            } else {
+                random.x0[i] = uniform01();
+                random.y0[i] = uniform01();
+                random.z0[i] = uniform01();
+            }
+            srand(p.seedface + g * 5);
+            int face = 7;
+            while (face > 6 || face < 1)
+                face = int(1 + uniform01() * 5. + 0.5);
+            random.face[i] = face;
+            srand(p.seedsign + g * 8);
+            random.sgnX[i] = draw_sign();
+            random.sgnY[i] = draw_sign();
+            random.sgnZ[i] = draw_sign();
         }
         if (myid == 0) {
             cout << "  " << endl;
