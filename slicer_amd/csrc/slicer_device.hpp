@@ -12,6 +12,11 @@
 
 #pragma clang fp contract(off)
 
+// rare exact paths: out of line by default (inlined, the compiler if-converts them into the hot stream)
+#ifndef SLICER_SLOWPATH
+#define SLICER_SLOWPATH __attribute__((noinline))
+#endif
+
 namespace slicer {
 
 constexpr int kMaxPlanes = 8;
@@ -67,7 +72,7 @@ __device__ __forceinline__ bool box_quotient_risky(double q)
 // exact quotient for the rare lanes that need it; out of line (and by value: no address-taken locals) so
 // that the IEEE division is really branched around -- inlined, the compiler if-converts it into every
 // particle's instruction stream
-__device__ __attribute__((noinline)) double div_by_box_exact(float r, double box, double q)
+__device__ SLICER_SLOWPATH double div_by_box_exact(float r, double box, double q)
 {
     return box_quotient_risky(q) ? (double)r / box : q;
 }
@@ -189,7 +194,7 @@ __device__ __forceinline__ float to_map_coord(double ang, const PassParams &P)
 struct Polar {
     double dec, ra;
 };
-__device__ __attribute__((noinline)) Polar polar_libm(double q, double Y, double Z)
+__device__ SLICER_SLOWPATH Polar polar_libm(double q, double Y, double Z)
 {
     Polar r;
     r.dec = asin(q);
