@@ -25,7 +25,13 @@ namespace slicer {
 
 namespace {
 
-constexpr int kK1Block = 512;   // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
+#ifndef SLICER_K1_BLOCK
+#define SLICER_K1_BLOCK 768
+#endif
+#ifndef SLICER_K1_WAVES_PER_SIMD
+#define SLICER_K1_WAVES_PER_SIMD 6
+#endif
+constexpr int kK1Block = SLICER_K1_BLOCK;  // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
 #ifndef SLICER_K1_PER_THREAD
 #define SLICER_K1_PER_THREAD 4
 #endif
@@ -113,7 +119,7 @@ __device__ __forceinline__ void load_round(const float *__restrict__ pos, const 
 }
 
 template <int MAS, bool POW2, bool HAS_MASS, bool VEC>
-__global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
+__global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
                                                         uint64_t n, PassParams P, BinGeom G,
                                                         float2 *__restrict__ cxy, unsigned short *__restrict__ cbin,
                                                         float *__restrict__ cm, unsigned *__restrict__ hist16,
@@ -235,23 +241,27 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
                 }
             }
             top -= take;
-            for (int p = 0; p < P.n_planes; p++) {  // selected-entry counters: one LDS add per wave and plane
-                const unsigned c = (unsigned)__popcll(__ballot(valid && plane == p));
-                if (c && lane == 0)
-                    atomicAdd(&s_cnt[p], c);
+            // selected-entry counters.  TSC emits every selected entry, so k_scan_bins takes them from the bin totals;
+            // NGP drops off-grid entries after selection and counts here: one LDS add per wave and plane
+            if (MAS == kNGP) {
+                for (int p = 0; p < P.n_planes; p++) {
+                    const unsigned c = (unsigned)__popcll(__ballot(valid && plane == p));
+                    if (c && lane == 0)
+                        atomicAdd(&s_cnt[p], c);
+                }
             }
             // Records go to the compact region of (unit, workgroup): [ (unit*gridDim.x + blockIdx.x) * batch, ... ).
             // One reservation per wave and distinct unit (a single returning LDS add by that unit's first lane).
             unsigned o = 0;
             unsigned long long todo = __ballot(emit);
             while (todo != 0ull) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const unsigned u = (unsigned)__shfl((int)unit, leader);
+                const int leader = __ffsll((long long)todo) - 1;  // wave-uniform: broadcasts are v_readlane
+                const unsigned u = (unsigned)__builtin_amdgcn_readlane((int)unit, leader);
                 const unsigned long long me = __ballot(emit && unit == u);
                 unsigned base = 0;
                 if ((int)lane == leader)
                     base = atomicAdd(&s_out[u], (unsigned)__popcll(me));
-                base = (unsigned)__shfl((int)base, leader);
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
                 if (emit && unit == u)
                     o = base + (unsigned)__popcll(me & ((1ull << lane) - 1ull));
                 todo &= ~me;
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(kK1Block, 4) void k_project_bin(const float *__rest
         bcount[(size_t)tid * gridDim.x + blockIdx.x] = s_out[tid];  // [unit][workgroup]
     if (tid == 0 && s_neg)
         atomicOr(T.neg_flag, 1);
-    if (tid < P.n_planes && s_cnt[tid])
+    if (MAS == kNGP && tid < P.n_planes && s_cnt[tid])
         atomicAdd(T.nsel[tid], (unsigned long long)s_cnt[tid]);
 }
 
@@ -334,8 +344,9 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
 }
 
 // K2b: exclusive scan over bins (single workgroup), base[nbins] = total record count
+// With count_planes set it also adds every plane's record count (= its selected entries on the TSC path) to nsel.
 __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__ total, unsigned *__restrict__ base,
-                                                    int nbins)
+                                                    int nbins, int count_planes, int bins_per_plane, Targets T)
 {
     __shared__ unsigned s_part[1024];
     const int tid = threadIdx.x;
@@ -359,6 +370,19 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__
     }
     if (tid == 1023)
         base[nbins] = s_part[1023];
+    if (tid < count_planes) {
+        // prefix(b) = records in bins [0, b): whole threads from s_part, the rest of thread b / per from total[]
+        unsigned pre[2];
+        for (int e = 0; e < 2; e++) {
+            const int b = (tid + e) * bins_per_plane, t = b / per;
+            unsigned v = t ? s_part[t - 1] : 0;
+            for (int i = t * per; i < b; i++)
+                v += total[i];
+            pre[e] = v;
+        }
+        if (pre[1] != pre[0])
+            atomicAdd(T.nsel[tid], (unsigned long long)(pre[1] - pre[0]));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,11 +768,13 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
 #undef K1
 }
 
-hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
+                           const Targets &T, hipStream_t s)
 {
     k_scan_blocks<<<(G.nbins + 63) / 64, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
                                                          nblocks, G.nbins);
-    k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins);
+    k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins, cfg.mas == kTSC ? n_planes : 0,
+                                   G.units_per_plane * G.tiles_per_unit, T);
     return hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SC
 
 struct slicer_handle_s {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipStream_t own = nullptr;
@@ -417,9 +418,10 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     if (G.n_units > kMaxUnits || G.tiles_per_unit > 8192 || nb > kMaxBins)
         return false;
     G.nbins = (int)nb;
-    // tuning overrides (SLICER_TILE_LOG2 / SLICER_TILE_H_LOG2 / SLICER_BIN_BATCH): the batch must be a multiple of
-    // one K1 round (2048 particles) and fit the 16-bit per-workgroup counters
-    G.batch = env_b ? std::min(std::max((env_b / 2048) * 2048, 2048), 32768) : kBinBatch;
+    // tuning overrides (SLICER_TILE_LOG2 / SLICER_TILE_H_LOG2 / SLICER_BIN_BATCH): the batch must keep every
+    // workgroup's first particle 16-byte aligned (multiple of 4; kept at a multiple of 1024) and fit the 16-bit
+    // per-workgroup counters
+    G.batch = env_b ? std::min(std::max((env_b / 1024) * 1024, 1024), 64512) : kBinBatch;
     if (G.tw_log2 < 3 || G.tw_log2 > 8 || G.th_log2 < 3 || G.th_log2 > 8)
         return false;
     return true;
@@ -521,6 +523,14 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
         return SLICER_OK;
     }
+    if (!getenv("SLICER_BIN_BATCH")) {
+        // K1 keeps two workgroups per CU resident: size the batch so that the workgroups of this call fill whole
+        // rounds of resident slots instead of leaving a short tail round
+        const uint64_t slots = 2ull * (uint64_t)h->num_cus;
+        const uint64_t rounds = (n + slots * kBinBatch - 1) / (slots * kBinBatch);
+        const uint64_t per = (n + slots * rounds - 1) / (slots * rounds);
+        G.batch = (int)std::min<uint64_t>(kBinBatch, std::max<uint64_t>(8192, (per + 1023) / 1024 * 1024));
+    }
     const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
     const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
     int rc;
@@ -537,7 +547,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCAN);
-        HIPCHK(h, launch_bin_scan(nblocks, G, W, h->stream));
+        HIPCHK(h, launch_bin_scan(cfg, nblocks, P.n_planes, G, W, T, h->stream));
     }
     {
         ProfScope ps(h, KN_SCATTER);
@@ -659,6 +669,9 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
         return rc;
     }
     h->stream = h->own;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        h->num_cus = cus;
     *out = h;
     return SLICER_OK;
 }

@@ -104,7 +104,7 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
     b[0] = __float_as_uint(wrap01(P.sgn[0] * (float)qx));  // sign flip is exact in any precision
     b[1] = __float_as_uint(wrap01(P.sgn[1] * (float)qy));
     b[2] = __float_as_uint(wrap01(P.sgn[2] * (float)qz));
-    // face permutation as bit selects with scalar masks (v_bfi_b32): out[a] = b[perm[a]]
+    // face permutation as bit selects with scalar masks: out[a] = b[perm[a]]
     const float v0 = __uint_as_float((b[0] & P.pm[0][0]) | (b[1] & P.pm[0][1]) | (b[2] & P.pm[0][2]));
     const float v1 = __uint_as_float((b[0] & P.pm[1][0]) | (b[1] & P.pm[1][1]) | (b[2] & P.pm[1][2]));
     const float v2 = __uint_as_float((b[0] & P.pm[2][0]) | (b[1] & P.pm[2][1]) | (b[2] & P.pm[2][2]));
@@ -122,25 +122,32 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
 // of glibc's and OCML's routines, which are used outside that range.  A1..A15 = (2k)!/(4^k k!^2 (2k+1)).
 // Both polynomials are evaluated as two interleaved Horner chains in w = z^2 (even and odd coefficients), which
 // halves the dependent-FMA depth; the series value is p = pe(w) + z*po(w).
+// r * w + c with the coefficient in a scalar register pair: the coefficients of both series would otherwise sit in 52
+// VGPRs (and cost a v_mov_b64 per term, v_fmac_f64 being destructive); s_mov of a literal is off the VALU port.
+__device__ __forceinline__ double fma_sc(double r, double w, double c)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(r), "v"(w), "s"(c));
+    return o;
+}
+
 __device__ __forceinline__ double asin_small(double x)
 {
     const double z = x * x, w = z * z;
     // A1..A15 split: even-index chain (A1, A3, ..., A15) and odd-index chain (A2, A4, ..., A14)
-    double pe = 0x1.31683bdef7bdfp-8;                 // A15
-    double po = 0x1.51ba308d3dcb1p-8;                 // A14
-    pe = fma(pe, w, 0x1.782dda12f684cp-8);            // A13
-    po = fma(po, w, 0x1.a6863d70a3d71p-8);            // A12
-    pe = fma(pe, w, 0x1.df3bd37a6f4dfp-8);            // A11
-    po = fma(po, w, 0x1.12ef3cf3cf3cfp-7);            // A10
-    pe = fma(pe, w, 0x1.3fde50d79435ep-7);            // A9
-    po = fma(po, w, 0x1.7a87878787878p-7);            // A8
-    pe = fma(pe, w, 0x1.c99999999999ap-7);            // A7
-    po = fma(po, w, 0x1.1c4ec4ec4ec4fp-6);            // A6
-    pe = fma(pe, w, 0x1.6e8ba2e8ba2e9p-6);            // A5
-    po = fma(po, w, 0x1.f1c71c71c71c7p-6);            // A4
-    pe = fma(pe, w, 0x1.6db6db6db6db7p-5);            // A3
-    po = fma(po, w, 0x1.3333333333333p-4);            // A2
-    pe = fma(pe, w, 0x1.5555555555555p-3);            // A1
+    double pe = fma_sc(0x1.31683bdef7bdfp-8, w, 0x1.782dda12f684cp-8);  // A15, A13
+    double po = fma_sc(0x1.51ba308d3dcb1p-8, w, 0x1.a6863d70a3d71p-8);  // A14, A12
+    pe = fma_sc(pe, w, 0x1.df3bd37a6f4dfp-8);         // A11
+    po = fma_sc(po, w, 0x1.12ef3cf3cf3cfp-7);         // A10
+    pe = fma_sc(pe, w, 0x1.3fde50d79435ep-7);         // A9
+    po = fma_sc(po, w, 0x1.7a87878787878p-7);         // A8
+    pe = fma_sc(pe, w, 0x1.c99999999999ap-7);         // A7
+    po = fma_sc(po, w, 0x1.1c4ec4ec4ec4fp-6);         // A6
+    pe = fma_sc(pe, w, 0x1.6e8ba2e8ba2e9p-6);         // A5
+    po = fma_sc(po, w, 0x1.f1c71c71c71c7p-6);         // A4
+    pe = fma_sc(pe, w, 0x1.6db6db6db6db7p-5);         // A3
+    po = fma_sc(po, w, 0x1.3333333333333p-4);         // A2
+    pe = fma_sc(pe, w, 0x1.5555555555555p-3);         // A1
     const double p = fma(po, z, pe);                  // A1 + A2 z + A3 z^2 + ...
     return fma(x * z, p, x);
 }
@@ -148,23 +155,52 @@ __device__ __forceinline__ double asin_small(double x)
 __device__ __forceinline__ double atan_small(double t)
 {
     const double z = t * t, w = z * z;
-    double pe = -0x1.0842108421084p-5;                // -1/31
-    double po = 0x1.1a7b9611a7b96p-5;                 // +1/29
-    pe = fma(pe, w, -0x1.2f684bda12f68p-5);           // -1/27
-    po = fma(po, w, 0x1.47ae147ae147bp-5);            // +1/25
-    pe = fma(pe, w, -0x1.642c8590b2164p-5);           // -1/23
-    po = fma(po, w, 0x1.8618618618618p-5);            // +1/21
-    pe = fma(pe, w, -0x1.af286bca1af28p-5);           // -1/19
-    po = fma(po, w, 0x1.e1e1e1e1e1e1ep-5);            // +1/17
-    pe = fma(pe, w, -0x1.1111111111111p-4);           // -1/15
-    po = fma(po, w, 0x1.3b13b13b13b14p-4);            // +1/13
-    pe = fma(pe, w, -0x1.745d1745d1746p-4);           // -1/11
-    po = fma(po, w, 0x1.c71c71c71c71cp-4);            // +1/9
-    pe = fma(pe, w, -0x1.2492492492492p-3);           // -1/7
-    po = fma(po, w, 0x1.999999999999ap-3);            // +1/5
-    pe = fma(pe, w, -0x1.5555555555555p-2);           // -1/3
+    double pe = fma_sc(-0x1.0842108421084p-5, w, -0x1.2f684bda12f68p-5);  // -1/31, -1/27
+    double po = fma_sc(0x1.1a7b9611a7b96p-5, w, 0x1.47ae147ae147bp-5);    // +1/29, +1/25
+    pe = fma_sc(pe, w, -0x1.642c8590b2164p-5);        // -1/23
+    po = fma_sc(po, w, 0x1.8618618618618p-5);         // +1/21
+    pe = fma_sc(pe, w, -0x1.af286bca1af28p-5);        // -1/19
+    po = fma_sc(po, w, 0x1.e1e1e1e1e1e1ep-5);         // +1/17
+    pe = fma_sc(pe, w, -0x1.1111111111111p-4);        // -1/15
+    po = fma_sc(po, w, 0x1.3b13b13b13b14p-4);         // +1/13
+    pe = fma_sc(pe, w, -0x1.745d1745d1746p-4);        // -1/11
+    po = fma_sc(po, w, 0x1.c71c71c71c71cp-4);         // +1/9
+    pe = fma_sc(pe, w, -0x1.2492492492492p-3);        // -1/7
+    po = fma_sc(po, w, 0x1.999999999999ap-3);         // +1/5
+    pe = fma_sc(pe, w, -0x1.5555555555555p-2);        // -1/3
     const double p = fma(po, z, pe);
     return fma(t * z, p, t);
+}
+
+// ---- correctly rounded sqrt and quotient without the range scaling ---------------------------------------------
+// The compiler's IEEE sequences (v_rsq_f64 / v_rcp_f64 + FMA iterations) wrap the same iterations in exponent
+// scaling (v_div_scale, v_div_fmas, v_div_fixup, v_ldexp + class tests) that only matters for operands near the
+// ends of the f64 range.  project() feeds them S in [2^-298, ~1e2] and quotients of f32-derived values, all far
+// from those ends, so the unscaled iterations return the same correctly rounded results; operands outside the
+// stated ranges take polar_exact().
+__device__ __forceinline__ double sqrt_midrange(double S)  // 2^-500 <= S <= 2^500
+{
+    const double y = __builtin_amdgcn_rsq(S);
+    double g = S * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, S);
+    g = fma(e, h, g);
+    e = fma(-g, g, S);
+    return fma(e, h, g);
+}
+
+__device__ __forceinline__ double div_midrange(double n, double d)  // 2^-500 <= |d| <= 2^500, n = 0 or 2^-500 <= |n| <= 2^500
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    const double q0 = n * y;
+    const double r = fma(-d, q0, n);
+    return fma(r, y, q0);
 }
 
 // (float)(ang / fov + 0.5)      densitymaps.cpp:385-386
@@ -194,10 +230,10 @@ __device__ __forceinline__ float to_map_coord(double ang, const PassParams &P)
 struct Polar {
     double dec, ra;
 };
-__device__ SLICER_SLOWPATH Polar polar_libm(double q, double Y, double Z)
+__device__ SLICER_SLOWPATH Polar polar_exact(double X, double Y, double Z)
 {
     Polar r;
-    r.dec = asin(q);
+    r.dec = asin(X / sqrt(X * X + Y * Y + Z * Z));
     r.ra = atan2(Y, Z);
     return r;
 }
@@ -210,14 +246,17 @@ __device__ __forceinline__ bool project(float x, float y, float z, int ni, int n
     double X = (double)xf - 0.5;
     double Y = (double)yf - 0.5;
     double Z = (double)z;
-    double d = sqrt(X * X + Y * Y + Z * Z);
-    double q = X / d;
+    // X, Y are 0 or >= 2^-25 in magnitude (differences of an f32 and 0.5); Z > 2^-150 below
+    const double S = X * X + Y * Y + Z * Z;
+    const bool mid = z > 0.0f && S < 0x1p100;  // false for NaN
+    const double d = sqrt_midrange(S);
+    const double q = div_midrange(X, d);
     double dec, ra;
-    if (fabs(q) <= 0.3125 && Z > 0.0 && fabs(Y) <= 0.3125 * Z && !(P.force_libm & 1)) {
+    if (mid && fabs(q) <= 0.3125 && fabs(Y) <= 0.3125 * Z && !(P.force_libm & 1)) {
         dec = asin_small(q);
-        ra = atan_small(Y / Z);
+        ra = atan_small(div_midrange(Y, Z));
     } else {
-        const Polar pl = polar_libm(q, Y, Z);
+        const Polar pl = polar_exact(X, Y, Z);
         dec = pl.dec;
         ra = pl.ra;
     }

@@ -98,7 +98,8 @@ size_t scatter_lds_bytes(const BinGeom &G, bool has_mass);
 hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
                               const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
                               hipStream_t s);
-hipError_t launch_bin_scan(int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s);
+hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
+                           const Targets &T, hipStream_t s);
 hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W,
                               hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
