@@ -160,6 +160,14 @@ int slicer_synth_positions(slicer_handle h, float *d_pos, uint64_t first, uint64
 int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t n, float *d_xs, float *d_ys,
                          int32_t *d_plane, uint64_t *d_src, uint64_t capacity, uint64_t *n_out);
 
+/* debug: the device arithmetic primitives of the projection on arbitrary operands (device pointers, n doubles each).
+ * op 0: out = sqrt(a)  (unscaled Newton iteration, valid for 2^-500 <= a <= 2^500)
+ * op 1: out = a / b    (same operand range; a may be 0)
+ * op 2: out = asin(a)  small-angle series, |a| <= 0.3125      op 3: out = atan(a), |a| <= 0.3125
+ * Lets the tests compare these with correctly rounded host results bit by bit (densitymaps.cpp:382-384 uses
+ * sqrt, /, asin, atan2 of libm). */
+int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n);
+
 /* per-kernel HIP-event timing (off by default; adds two event records per launch) */
 int slicer_profile_enable(slicer_handle h, int on);
 int slicer_profile_reset(slicer_handle h);

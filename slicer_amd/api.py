@@ -231,6 +231,21 @@ class Slicer:
                 self.free(p)
         return cnt.value, xs, ys, pl, src
 
+    def debug_math(self, op, a, b=None):
+        """Device sqrt (op 0), quotient (1), small-angle asin (2) / atan (3) of float64 arrays; see slicer_amd.h."""
+        a = np.ascontiguousarray(a, np.float64)
+        n = a.size
+        d_a = self.to_device(a)
+        d_b = self.to_device(np.ascontiguousarray(b, np.float64)) if b is not None else None
+        d_o = self.malloc(8 * max(n, 1))
+        try:
+            self._chk(_L.slicer_debug_math(self._h, int(op), C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_o), n))
+            return self.to_host(d_o, n, np.float64)
+        finally:
+            for p in (d_a, d_b, d_o):
+                if p is not None:
+                    self.free(p)
+
     def profile_enable(self, on=True):
         self._chk(_L.slicer_profile_enable(self._h, int(bool(on))))
 

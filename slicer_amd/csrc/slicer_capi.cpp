@@ -1138,6 +1138,18 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
     return SLICER_OK;
 }
 
+int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (op < 0 || op > 3 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
+        return fail(h, SLICER_ERR_ARG, "slicer_debug_math: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_debug_math(op, d_a, d_b, d_out, n, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLICER_OK;
+}
+
 int slicer_profile_enable(slicer_handle h, int on)
 {
     if (!h)

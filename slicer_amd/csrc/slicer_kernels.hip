@@ -503,6 +503,30 @@ hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_debug_math(int op, const double *__restrict__ a, const double *__restrict__ b,
+                                                    double *__restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double r;
+    switch (op) {
+    case 0: r = sqrt_midrange(a[i]); break;
+    case 1: r = div_midrange(a[i], b[i]); break;
+    case 2: r = asin_small(a[i]); break;
+    default: r = atan_small(a[i]); break;
+    }
+    out[i] = r;
+}
+
+hipError_t launch_debug_math(int op, const double *d_a, const double *d_b, double *d_out, uint64_t n, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    k_debug_math<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(op, d_a, d_b, d_out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_thin_count(const float *d_pos, uint64_t n, const PassParams &P, unsigned *counts,
                              unsigned long long *base, int *neg_flag, hipStream_t s)
 {

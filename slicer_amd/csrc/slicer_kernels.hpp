@@ -60,6 +60,7 @@ hipError_t launch_fold_ngp(const FoldArgs &A, hipStream_t s);
 hipError_t launch_synth(float *d_pos, uint64_t first, uint64_t count, double box, uint64_t seed, int clustered,
                         hipStream_t s);
 
+hipError_t launch_debug_math(int op, const double *d_a, const double *d_b, double *d_out, uint64_t n, hipStream_t s);
 hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams &P, float *d_xs, float *d_ys,
                                 int32_t *d_plane, uint64_t *d_src, uint64_t capacity, unsigned long long *d_count,
                                 int *neg_flag, hipStream_t s);

@@ -173,6 +173,66 @@ def test_small_angle_series_equals_libm_path(S):
     assert bad <= 1, f"{bad} of {2 * outs[0][0]} coordinates differ between the series and libm"
 
 
+def _adversarial_mantissas(rng, n):
+    """f64 values in [1, 2) whose mantissas stress the last rounding step: random, all-ones / all-zero tails,
+    values next to powers of two."""
+    m = rng.integers(0, 1 << 52, n, dtype=np.uint64)
+    k = n // 4
+    m[:k] |= np.uint64((1 << 26) - 1)                       # long run of ones at the bottom
+    m[k:2 * k] &= ~np.uint64((1 << 26) - 1)                 # long run of zeros at the bottom
+    m[2 * k:3 * k] = rng.integers(0, 64, k, dtype=np.uint64)            # just above a power of two
+    m[3 * k:3 * k + k // 2] = np.uint64((1 << 52) - 1) - rng.integers(0, 64, k // 2, dtype=np.uint64)  # just below
+    return (m | np.uint64(1023 << 52)).view(np.float64)
+
+
+def test_device_sqrt_is_correctly_rounded(S):
+    """sqrt_midrange() (v_rsq_f64 + unscaled FMA iterations) against the host's IEEE sqrt, bit for bit: random and
+    adversarial mantissas over the exponent range project() can feed it (S >= 2^-298), perfect squares and their
+    neighbours."""
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    a = _adversarial_mantissas(rng, n) * np.exp2(rng.integers(-300, 101, n)).astype(np.float64)
+    r = rng.integers(1, 1 << 26, 1 << 18).astype(np.float64)
+    sq = r * r
+    a = np.concatenate([a, sq, np.nextafter(sq, 0), np.nextafter(sq, np.inf), rng.uniform(0.0, 12.0, n)])
+    got = S.debug_math(0, a)
+    want = np.sqrt(a)
+    bad = int((got.view(np.uint64) != want.view(np.uint64)).sum())
+    assert bad == 0, f"{bad} of {a.size} square roots differ from the correctly rounded value"
+
+
+def test_device_quotient_is_correctly_rounded(S):
+    """div_midrange() (v_rcp_f64 + unscaled FMA iterations) against the host's IEEE division, bit for bit, on the
+    operand classes of project(): X / d and Y / Z with numerators 0 or in [2^-25, 2^5], denominators in [2^-149, 2^5]."""
+    rng = np.random.default_rng(6)
+    n = 1 << 21
+    num = _adversarial_mantissas(rng, n) * np.exp2(rng.integers(-25, 6, n)).astype(np.float64) * rng.choice([-1.0, 1.0], n)
+    den = _adversarial_mantissas(rng, n)[::-1] * np.exp2(rng.integers(-149, 6, n)).astype(np.float64)
+    # f32-derived operands as in the kernel: (f32 - 0.5) / f32, plus exact and almost exact quotients
+    y = rng.random(n).astype(np.float32).astype(np.float64) - 0.5
+    z = (rng.random(n).astype(np.float32) * 4 + np.float32(1e-3)).astype(np.float64)
+    q = rng.integers(1, 1 << 20, n).astype(np.float64)
+    d = rng.integers(1, 1 << 20, n).astype(np.float64)
+    a = np.concatenate([num, y, q * d, q * d + 1, np.zeros(16)])
+    b = np.concatenate([den, z, d, d, den[:16]])
+    got = S.debug_math(1, a, b)
+    want = a / b
+    bad = int((got.view(np.uint64) != want.view(np.uint64)).sum())
+    assert bad == 0, f"{bad} of {a.size} quotients differ from the correctly rounded value"
+
+
+def test_device_series_accuracy(S):
+    """asin_small / atan_small against numpy's libm in float64 on |x| <= 0.3125: at most 1 ulp apart (both sides are
+    ~1 ulp routines; the f32 map coordinate absorbs this, see test_small_angle_series_equals_libm_path)."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-0.3125, 0.3125, 1 << 20), [0.0, 0.3125, -0.3125, 1e-300, 2.0 ** -30]])
+    for op, fn in ((2, np.arcsin), (3, np.arctan)):
+        got, want = S.debug_math(op, x), fn(x)
+        ulp = np.abs(got - want) / np.spacing(np.abs(want))
+        assert ulp.max() <= 1.0, (op, ulp.max())
+        assert (ulp == 0).mean() > 0.9
+
+
 def test_large_fov_uses_libm_path(S):
     """fov = 1.2 rad: arguments leave the series' range; parity with the oracle must hold there too."""
     files = [one_type_file(200000)]
