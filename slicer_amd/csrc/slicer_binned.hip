@@ -38,6 +38,9 @@ constexpr int kK1Block = SLICER_K1_BLOCK;  // project+bin workgroup: 8 waves, tw
 constexpr int kPerThread = SLICER_K1_PER_THREAD;  // particles per lane and round (4: three dwordx4 loads)
 constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 workgroup
 
+#ifndef SLICER_LDS_BARRIER
+#define SLICER_LDS_BARRIER 1
+#endif
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
 // Reserve one slot per lane with pred set, one LDS atomic per wave.
@@ -58,6 +61,18 @@ __device__ __forceinline__ unsigned wave_reserve(bool pred, unsigned *counter)
 
 template <typename T>
 __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory queue
+// (s_waitcnt vmcnt(0)), which stalls every wave on loads and stores that nothing behind the barrier depends on.
+// Use where the barrier protects LDS contents; register dependences on loaded values are tracked by the compiler.
+__device__ __forceinline__ void lds_barrier()
+{
+#if SLICER_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 
 }  // namespace
 
@@ -388,12 +403,24 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__
 // ---------------------------------------------------------------------------------------------
 // K3: scatter records into their bin runs
 // ---------------------------------------------------------------------------------------------
-// One workgroup per (unit, K1 workgroup) pair (a unit is a plane, or a band of tile rows of a plane on large maps).  Its records are counting-sorted by tile in LDS (sub-batches of
-// kSortBatch records), so that the records of one (unit, tile) run are stored by adjacent lanes: a plain
-// scatter issues one 32-byte sector write per 8-byte record (measured write amplification 4.2x), runs of
-// 3-8 records cut that to 1-2 sectors per run.
-constexpr int kSortBlock = 1024;
+// One work item per (unit, K1 workgroup) pair (a unit is a plane, or a band of tile rows of a plane on large maps),
+// taken by persistent 512-thread workgroups, two per CU.  An item's records are counting-sorted by tile in LDS
+// (sub-batches of kSortBatch records, exchanged kSortStage at a time), so that the records of one (unit, tile) run
+// are stored by adjacent lanes: a plain scatter issues one 32-byte sector write per 8-byte record (measured write
+// amplification 4.2x), runs of 3-8 records cut that to 1-2 sectors per run.  The phases of an item (loads, scan,
+// LDS exchange, stores) are serial inside a workgroup; the second workgroup of the CU fills the gaps (81 -> 70 us).
+#ifndef SLICER_K3_BLOCK
+#define SLICER_K3_BLOCK 512
+#endif
+constexpr int kSortBlock = SLICER_K3_BLOCK;
 constexpr int kSortBatch = 8192;
+#ifndef SLICER_K3_STAGE
+#define SLICER_K3_STAGE 4096
+#endif
+#ifndef SLICER_K3_WAVES
+#define SLICER_K3_WAVES 4  // waves per SIMD the register budget allows: two 512-thread workgroups per CU
+#endif
+constexpr int kSortStage = SLICER_K3_STAGE;  // sorted records staged in LDS at a time
 
 __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s_wave /*[kSortBlock/64]*/)
 {
@@ -408,18 +435,19 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s
     const int w = threadIdx.x >> 6;
     if (lane_id() == 63)
         s_wave[w] = x;
-    __syncthreads();
+    lds_barrier();
     unsigned off = 0;
     for (int k = 0; k < w; k++)
         off += s_wave[k];
-    __syncthreads();
+    lds_barrier();
     return off + x - v;
 }
 
 template <bool HAS_MASS>
-__global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__restrict__ cxy,
+__global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(const float2 *__restrict__ cxy,
                                                             const unsigned short *__restrict__ cbin,
                                                             const float *__restrict__ cm,
+                                                            const unsigned *__restrict__ hist16w,
                                                             const unsigned *__restrict__ prefix,
                                                             const unsigned *__restrict__ base,
                                                             const unsigned *__restrict__ bcount, int nblocks,
@@ -430,100 +458,130 @@ __global__ __launch_bounds__(kSortBlock) void k_bin_scatter(const float2 *__rest
     const int tpp = G.tiles_per_unit;
     const int tw = (tpp + 1) >> 1;    // words of a packed u16 table
     unsigned *cnt = smem_sc;          // [tpp] u16 x2 per word: records of the sub-batch per tile (<= kSortBatch)
-    unsigned *pos0 = cnt + tw;        // [tpp] u16 x2 per word: running LDS position (ends at start + cnt)
-    unsigned *cur = pos0 + tw;        // [tpp] u32 global write cursor of this unit
-    float2 *sorted_xy = reinterpret_cast<float2 *>(cur + tpp + (tpp & 1));
-    unsigned short *sorted_tile = reinterpret_cast<unsigned short *>(sorted_xy + kSortBatch);
-    float *sorted_m = reinterpret_cast<float *>(sorted_tile + kSortBatch);  // HAS_MASS only
+    unsigned *pos = cnt + tw;         // [tpp] u32 running sorted position of each tile (ends at start + cnt)
+    unsigned *cur = pos + tpp;        // [tpp] u32 global write cursor of this unit minus the tile's sorted start
+    float2 *sorted_xy = reinterpret_cast<float2 *>(cur + tpp + (tw & 1));
+    unsigned short *sorted_tile = reinterpret_cast<unsigned short *>(sorted_xy + kSortStage);
+    float *sorted_m = reinterpret_cast<float *>(sorted_tile + kSortStage);  // HAS_MASS only
     __shared__ unsigned s_wave[kSortBlock / 64];
 
     const int tid = threadIdx.x;
-    // workgroup -> (unit, K1 workgroup); XCD-aware order inside the unit (speed only, see k_project_bin notes)
+    // Persistent workgroups: each takes the (unit, K1 workgroup) items b, b + gridDim.x, ...  item -> (unit, K1
+    // workgroup) keeps an XCD's items on a contiguous range of K1 workgroups (gridDim.x is a multiple of 8, so
+    // item & 7 is this workgroup's XCD): runs of one tile written by neighbouring K1 workgroups then meet in the
+    // same L2.
     const int per_unit = 8 * ((nblocks + 7) / 8);
-    const int plane = blockIdx.x / per_unit;  // the unit index (a whole plane unless the map is large)
-    const int u = blockIdx.x % per_unit;
     const int per_xcd = per_unit / 8;
-    const int lb = (u & 7) * per_xcd + (u >> 3);
-    if (lb >= nblocks)
-        return;
-    const unsigned count = bcount[(size_t)plane * nblocks + lb];
-    if (count == 0)
-        return;
-    const unsigned *row = prefix + (size_t)lb * G.nbins + (size_t)plane * tpp;
-    const unsigned *brow = base + (size_t)plane * tpp;
-    for (int i = tid; i < tpp; i += kSortBlock)
-        cur[i] = brow[i] + row[i];
-    const uint64_t r0 = ((uint64_t)plane * nblocks + lb) * (uint64_t)G.batch;
     const int per = (tpp + kSortBlock - 1) / kSortBlock;  // tiles per lane in the scan (<= 8)
     auto get16 = [](const unsigned *tab, unsigned t) { return (tab[t >> 1] >> ((t & 1u) * 16u)) & 0xFFFFu; };
-
     constexpr int R = kSortBatch / kSortBlock;  // records per lane and sub-batch
-    for (unsigned s0 = 0; s0 < count; s0 += kSortBatch) {
-        const unsigned nsub = count - s0 < (unsigned)kSortBatch ? count - s0 : (unsigned)kSortBatch;
-        for (int i = tid; i < tw; i += kSortBlock)
-            cnt[i] = 0;
-        __syncthreads();
-        unsigned tile[R];
-        float2 xy[R];
-        float m[R];
+    for (int item = blockIdx.x; item < G.n_units * per_unit; item += gridDim.x) {
+        const int plane = item / per_unit;  // the unit index (a whole plane unless the map is large)
+        const int u = item % per_unit;
+        const int lb = (u & 7) * per_xcd + (u >> 3);
+        if (lb >= nblocks)
+            continue;
+        const unsigned count = bcount[(size_t)plane * nblocks + lb];
+        if (count == 0)
+            continue;
+        lds_barrier();  // the previous item's tables are no longer read
+        const unsigned *row = prefix + (size_t)lb * G.nbins + (size_t)plane * tpp;
+        const unsigned *brow = base + (size_t)plane * tpp;
+        for (int i = tid; i < tpp; i += kSortBlock)
+            cur[i] = brow[i] + row[i];
+        const uint64_t r0 = ((uint64_t)plane * nblocks + lb) * (uint64_t)G.batch;
+
+        // A region that fits one sub-batch (the usual case) needs no counting pass: its per-tile counts are this K1
+        // workgroup's histogram row, already in the packed layout of cnt (needs the unit's first bin word-aligned).
+        const bool single = count <= (unsigned)kSortBatch && (((unsigned)plane * (unsigned)tpp) & 1u) == 0u;
+        for (unsigned s0 = 0; s0 < count; s0 += kSortBatch) {
+            const unsigned nsub = count - s0 < (unsigned)kSortBatch ? count - s0 : (unsigned)kSortBatch;
+            if (!single) {
+                for (int i = tid; i < tw; i += kSortBlock)
+                    cnt[i] = 0;
+                lds_barrier();
+            }
+            unsigned tile[R];
+            float2 xy[R];
+            float m[R];
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            const unsigned i = (unsigned)k * kSortBlock + tid;
-            if (i < nsub) {
-                tile[k] = cbin[r0 + s0 + i];
-                xy[k] = cxy[r0 + s0 + i];
-                if (HAS_MASS)
-                    m[k] = cm[r0 + s0 + i];
-                atomicAdd(&cnt[tile[k] >> 1], 1u << ((tile[k] & 1u) * 16u));
-            }
-        }
-        __syncthreads();
-        // exclusive scan of cnt -> pos0; lane handles tiles [tid*per, tid*per + per)
-        {
-            unsigned sum = 0;
-            for (int j = 0; j < per; j++) {
-                const unsigned t = (unsigned)(tid * per + j);
-                if ((int)t < tpp)
-                    sum += get16(cnt, t);
-            }
-            unsigned e = block_exclusive_scan(sum, s_wave);
-            // packed writes: a lane owns whole words only if per is even; use atomics-free half-word stores
-            unsigned short *pos16 = reinterpret_cast<unsigned short *>(pos0);
-            for (int j = 0; j < per; j++) {
-                const unsigned t = (unsigned)(tid * per + j);
-                if ((int)t < tpp) {
-                    pos16[t] = (unsigned short)e;
-                    e += get16(cnt, t);
+            for (int k = 0; k < R; k++) {
+                const unsigned i = (unsigned)k * kSortBlock + tid;
+                if (i < nsub) {
+                    tile[k] = cbin[r0 + s0 + i];
+                    xy[k] = cxy[r0 + s0 + i];
+                    if (HAS_MASS)
+                        m[k] = cm[r0 + s0 + i];
+                    if (!single)
+                        atomicAdd(&cnt[tile[k] >> 1], 1u << ((tile[k] & 1u) * 16u));
                 }
             }
-        }
-        __syncthreads();
+            if (single) {
+                const unsigned *hrow =
+                    hist16w + (size_t)lb * (size_t)((G.nbins + 1) >> 1) + (((size_t)plane * tpp) >> 1);
+                for (int i = tid; i < tw; i += kSortBlock)
+                    cnt[i] = (i == tw - 1 && (tpp & 1)) ? (hrow[i] & 0xFFFFu) : hrow[i];
+            }
+            lds_barrier();
+            // exclusive scan of cnt -> pos; lane handles tiles [tid*per, tid*per + per).  The cursor is stored minus
+            // the tile's sorted start, so that the write-out needs a single table: dst = cur[t] + sorted position.
+            {
+                unsigned sum = 0;
+                for (int j = 0; j < per; j++) {
+                    const unsigned t = (unsigned)(tid * per + j);
+                    if ((int)t < tpp)
+                        sum += get16(cnt, t);
+                }
+                unsigned e = block_exclusive_scan(sum, s_wave);
+                for (int j = 0; j < per; j++) {
+                    const unsigned t = (unsigned)(tid * per + j);
+                    if ((int)t < tpp) {
+                        pos[t] = e;
+                        cur[t] -= e;
+                        e += get16(cnt, t);
+                    }
+                }
+            }
+            lds_barrier();
+            // sorted position of every record (one returning LDS add), kept in the upper half of tile[]
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            const unsigned i = (unsigned)k * kSortBlock + tid;
-            if (i < nsub) {
-                const unsigned sh = (tile[k] & 1u) * 16u;
-                const unsigned p = (atomicAdd(&pos0[tile[k] >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                sorted_xy[p] = xy[k];
-                sorted_tile[p] = (unsigned short)tile[k];
-                if (HAS_MASS)
-                    sorted_m[p] = m[k];
+            for (int k = 0; k < R; k++) {
+                const unsigned i = (unsigned)k * kSortBlock + tid;
+                if (i < nsub)
+                    tile[k] |= atomicAdd(&pos[tile[k]], 1u) << 16;
+                else
+                    tile[k] = 0xFFFF0000u;  // position 65535: outside every staging round
+            }
+            // exchange through LDS and write out, kSortStage sorted positions at a time (the staging area is what
+            // limits the workgroups per CU)
+            for (unsigned lo = 0; lo < nsub; lo += kSortStage) {
+                lds_barrier();  // positions final (first round) / previous round's staging consumed
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const unsigned q = (tile[k] >> 16) - lo;
+                    if (q < (unsigned)kSortStage) {
+                        sorted_xy[q] = xy[k];
+                        sorted_tile[q] = (unsigned short)(tile[k] & 0xFFFFu);
+                        if (HAS_MASS)
+                            sorted_m[q] = m[k];
+                    }
+                }
+                lds_barrier();
+                const unsigned hi = nsub - lo < (unsigned)kSortStage ? nsub - lo : (unsigned)kSortStage;
+                for (unsigned q = tid; q < hi; q += kSortBlock) {
+                    const unsigned dst = cur[sorted_tile[q]] + lo + q;
+                    sxy[dst] = sorted_xy[q];
+                    if (HAS_MASS)
+                        sm[dst] = sorted_m[q];
+                }
+            }
+            if (!single) {
+                lds_barrier();
+                // next sub-batch: cursor = old cursor + count = (cursor - start) + (start + count) = cur + pos
+                for (int i = tid; i < tpp; i += kSortBlock)
+                    cur[i] += pos[i];
             }
         }
-        __syncthreads();
-        for (unsigned p = tid; p < nsub; p += kSortBlock) {
-            const unsigned t = sorted_tile[p];
-            // pos0[t] now points past the tile's run: its start is pos0[t] - cnt[t]  (mod 2^16: nsub = 8192 can
-            // make the last tile's end 8192, still < 65536, so no wrap)
-            const unsigned dst = cur[t] + (p - (get16(pos0, t) - get16(cnt, t)));
-            sxy[dst] = sorted_xy[p];
-            if (HAS_MASS)
-                sm[dst] = sorted_m[p];
-        }
-        __syncthreads();
-        for (int i = tid; i < tpp; i += kSortBlock)
-            cur[i] += get16(cnt, (unsigned)i);
-        // cnt is re-zeroed at the top of the loop after the barrier above
     }
 }
 
@@ -781,13 +839,15 @@ hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, cons
 size_t scatter_lds_bytes(const BinGeom &G, bool has_mass)
 {
     const size_t tpp = (size_t)G.tiles_per_unit, tw = (tpp + 1) >> 1;
-    return 4 * (2 * tw + tpp + (tpp & 1)) + (size_t)kSortBatch * (8 + 2 + (has_mass ? 4 : 0));
+    return 4 * (tw + 2 * tpp + (tw & 1)) + (size_t)kSortStage * (8 + 2 + (has_mass ? 4 : 0));
 }
 
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const BinGeom &G, const BinWorkspace &W,
+                              hipStream_t s)
 {
     const size_t lds = scatter_lds_bytes(G, has_mass);
-    const int grid = G.n_units * 8 * ((nblocks + 7) / 8);
+    const int items = G.n_units * 8 * ((nblocks + 7) / 8);
+    const int grid = std::min(items, std::max(8, max_workgroups / 8 * 8));
     const unsigned short *cb = reinterpret_cast<const unsigned short *>(W.cbin);
     hipError_t e;
     if (has_mass) {
@@ -795,14 +855,14 @@ hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, cons
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<true><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<true><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                           W.sm);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<false><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<false><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                            W.sm);
     }
     return hipGetLastError();

@@ -427,6 +427,14 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     return true;
 }
 
+// persistent K3 workgroups: two per CU (their LDS and registers allow it), so that one workgroup's load / LDS /
+// store phases overlap the other's; SLICER_K3_PER_CU overrides (tuning knob)
+static int scatter_workgroups(slicer_handle h)
+{
+    static const int per_cu = getenv("SLICER_K3_PER_CU") ? std::max(1, atoi(getenv("SLICER_K3_PER_CU"))) : 2;
+    return h->num_cus * per_cu;
+}
+
 int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, const BinGeom &G, BinWorkspace &W)
 {
     const uint64_t nb = (n + G.batch - 1) / G.batch;
@@ -551,7 +559,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, G, W, h->stream));
+        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, scatter_workgroups(h), G, W, h->stream));
     }
     if (slot == 0) {
         h->pend_key = key;

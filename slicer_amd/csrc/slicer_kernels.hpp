@@ -101,7 +101,7 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
                               hipStream_t s);
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s);
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, const BinGeom &G, const BinWorkspace &W,
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const BinGeom &G, const BinWorkspace &W,
                               hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
