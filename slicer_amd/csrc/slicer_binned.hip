@@ -667,34 +667,16 @@ __global__ __launch_bounds__(1024) void k_build_items(PendingList L, int nbins, 
 
 constexpr int kTileBlock = 1024;
 
-template <int MAS, int ACC, bool POW2, bool HAS_MASS>
-__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
-                                                             TileItems I)
+// Deposit this work item's share of every pending chunk into the LDS tile.  CHECK = false for tiles whose halo
+// lies inside the map (all but the border tiles): the per-cell map-edge tests and their exec-mask bookkeeping go.
+template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK>
+__device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
+                                                typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
+                                                unsigned nparts, int x0, int y0, int W)
 {
-    using acc_t = typename AccT<ACC>::type;
     using lds_t = typename AccT<ACC>::lds;
-    extern __shared__ unsigned char smem_raw[];
-    lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
-
-    if (blockIdx.x >= *I.n_items)
-        return;
-    const uint2 item = I.items[blockIdx.x];
-    const unsigned bin = item.x, part = item.y, nparts = I.nparts[bin];
-    const int unit = bin / G.tiles_per_unit;
-    const int t = bin % G.tiles_per_unit;
-    const int plane = unit / G.units_per_plane;
-    const int band = unit % G.units_per_plane;
-    const int x0 = (t % G.ntx) << G.tw_log2;
-    const int y0 = (band * G.rows_per_unit + t / G.ntx) << G.th_log2;
-    const int W = (1 << G.tw_log2) + 2, H = (1 << G.th_log2) + 2;
-    const int cells = W * H;
     const int tid = threadIdx.x;
     const int nn = P.nn;
-
-    for (int i = tid; i < cells; i += kTileBlock)
-        tile[i] = (lds_t)0;
-    __syncthreads();
-
     constexpr int U = 4;  // records in flight per lane
     for (int c = 0; c < L.n; c++) {
         // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts)
@@ -744,23 +726,60 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
                         wx[a] = sq * wx[a];
                         wy[a] = sq * wy[a];
                     }
+                    lds_t *cell0 = tile + (gy - y0) * W + (gx - x0);  // cell (gx - 1, gy - 1)
 #pragma unroll
                     for (int b = 0; b < 3; b++) {
                         const int py = gy + b - 1;
-                        if (py < 0 || py >= nn)
+                        if (CHECK && (py < 0 || py >= nn))
                             continue;
 #pragma unroll
                         for (int a = 0; a < 3; a++) {
                             const int px = gx + a - 1;
-                            if (px < 0 || px >= nn)
+                            if (CHECK && (px < 0 || px >= nn))
                                 continue;
-                            lds_add<ACC>(tile + (py - y0 + 1) * W + (px - x0 + 1), wx[a] * wy[b], P);
+                            lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P);
                         }
                     }
                 }
             }
         }
     }
+}
+
+template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
+                                                             TileItems I)
+{
+    using acc_t = typename AccT<ACC>::type;
+    using lds_t = typename AccT<ACC>::lds;
+    extern __shared__ unsigned char smem_raw[];
+    lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
+
+    if (blockIdx.x >= *I.n_items)
+        return;
+    const uint2 item = I.items[blockIdx.x];
+    const unsigned bin = item.x, part = item.y, nparts = I.nparts[bin];
+    const int unit = bin / G.tiles_per_unit;
+    const int t = bin % G.tiles_per_unit;
+    const int plane = unit / G.units_per_plane;
+    const int band = unit % G.units_per_plane;
+    const int x0 = (t % G.ntx) << G.tw_log2;
+    const int y0 = (band * G.rows_per_unit + t / G.ntx) << G.th_log2;
+    const int W = (1 << G.tw_log2) + 2, H = (1 << G.th_log2) + 2;
+    const int cells = W * H;
+    const int tid = threadIdx.x;
+    const int nn = P.nn;
+
+    for (int i = tid; i < cells; i += kTileBlock)
+        tile[i] = (lds_t)0;
+    __syncthreads();
+
+    // the halo [x0 - 1, x0 + W - 2] x [y0 - 1, y0 + H - 2] inside the map: no cell of this tile needs the edge test
+    const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
+    if (MAS == kNGP || interior)
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W);
+    else
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W);
     __syncthreads();
 
     // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)

@@ -262,6 +262,10 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
     P.nn_d = (double)d.npix;
     P.half_dl = 0.5 * P.dl;
     P.onehalf_dl = 0.5 * 3.0 * P.dl;
+    P.dl_f = (float)P.dl;
+    P.nn_f = (float)P.nn_d;
+    P.half_dl_f = (float)P.half_dl;
+    P.onehalf_dl_f = (float)P.onehalf_dl;
     P.mconst = (float)f.massarr[type];  // densitymaps.cpp:372
     P.sm_const = sqrtf(P.mconst);       // glibc sqrtf is correctly rounded, as std::sqrt(float)
     int e = d.want_type_maps ? h->fixed_exp[type] : h->fixed_exp_shared;

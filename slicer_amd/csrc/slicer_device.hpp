@@ -49,6 +49,7 @@ struct PassParams {
     double nn_d;     // (double)nn
     double half_dl;  // 0.5 * dl
     double onehalf_dl;  // 0.5 * 3.0 * dl
+    float dl_f, nn_f, half_dl_f, onehalf_dl_f;  // the same as f32: exact when nn is a power of two (pow2 paths only)
     // --- mass (densitymaps.cpp:358-372) ---
     float mconst;    // (float)massarr[t]
     float sm_const;  // sqrtf(mconst), IEEE correctly rounded
@@ -280,17 +281,44 @@ __device__ __forceinline__ bool surely_outside_fov(float x, float y, float z, co
 }
 
 // floor(x / dl) as int.   utilities.cpp:69-70
+// POW2 (dl = 2^-k): x / dl = x * 2^k, an exact scaling in f32 as well as in f64, so the f32 product and floorf()
+// give the reference's double-precision result without any fp64 instruction.
 template <bool POW2>
 __device__ __forceinline__ int grid_index(float v, const PassParams &P)
 {
-    double q = POW2 ? (double)v * P.nn_d : (double)v / P.dl;
-    return (int)floor(q);
+    if (POW2)
+        return (int)floorf(v * P.nn_f);
+    return (int)floor((double)v / P.dl);
 }
 
 // TSC weights of the three cells g-1, g, g+1 along one axis.   utilities.cpp:4-16, 82-88
+// General case: the reference's mixed f32/f64 sequence, operation by operation.
+// POW2 (dl = 2^-k): every fp64 step of that sequence is exact or rounds once to f32, so the same values come out of
+// f32 instructions alone (fp64 VALU ops issue at half the f32 rate and the conversions are extra instructions):
+//   c  = (float)((p + 0.5) * dl)     (p + 0.5) * 2^-k is exact                 = ((float)p + 0.5f) * dl, c(g +- 1) = c(g) +- dl
+//   u  = (float)((double)A / dl)     exact scaling                             = A * nn
+//   A <= 0.5 dl, A <= 1.5 dl         both thresholds are f32 values            = f32 compares (decided statically, below)
+//   (float)(0.75 - (double)(u*u))    the f64 difference is exact (u*u < 2^-2 has 24 bits; below 2^-50 both give 0.75f)
+//                                                                              = 0.75f - u*u
+//   t = 1.5 - (double)u              exact, and a multiple of 2^-24 <= 1: an f32  = 1.5f - u
+//   (float)(0.5 * (t * t))           t*t exact in f64, one rounding to f32; halving commutes with it  = 0.5f * (t * t)
 template <bool POW2>
 __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, float w[3])
 {
+    if (POW2) {
+        // g = floor(v * nn) for this same v, so |v - c| <= 0.5 dl at the centre cell and 0.5 dl <= |v - c| <= 1.5 dl at
+        // its neighbours (rounding is monotonic and the bounds are f32 values): the reference's branch is known, and
+        // at |v - c| = 0.5 dl, where it would take the other one, both formulas give exactly 0.5.
+        const float cg = ((float)g + 0.5f) * P.dl_f;
+        const float u0 = fabsf(v - (cg - P.dl_f)) * P.nn_f;
+        const float u1 = fabsf(v - cg) * P.nn_f;
+        const float u2 = fabsf(v - (cg + P.dl_f)) * P.nn_f;
+        const float t0 = 1.5f - u0, t2 = 1.5f - u2;
+        w[0] = 0.5f * (t0 * t0);
+        w[1] = 0.75f - u1 * u1;
+        w[2] = 0.5f * (t2 * t2);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         int p = g + a - 1;
@@ -298,7 +326,7 @@ __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, fl
         float D = v - c;
         float A = fabsf(D);
         double Ad = (double)A;
-        float u = (float)(POW2 ? Ad * P.nn_d : Ad / P.dl);
+        float u = (float)(Ad / P.dl);
         float W;
         if (Ad <= P.half_dl) {
             float uu = u * u;

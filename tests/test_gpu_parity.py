@@ -303,6 +303,29 @@ def test_tsc_exact_accumulators_match_f64_sum(S, algo):
         assert frac < 1e-3, frac
 
 
+@pytest.mark.parametrize("npix", [256, 100, 2048])
+@pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
+def test_tsc_weights_bitwise_through_fixed_point(S, npix, algo):
+    """Every TSC contribution (weight() products of utilities.cpp:4-16,82-88) bit for bit: the FIXED64 map is the
+    integer sum of rint(c * 2^46) over the contributions c, so it must equal the same integer sum of the restated
+    f32 contributions exactly -- one wrong bit in a weight of ordinary size moves the sum by thousands of units.
+    npix 256/2048 take the power-of-two arithmetic of the kernels, 100 the general one."""
+    fov, ld, ld2, m = 0.25, 3.0, 3.5, 0.0123
+    f = one_type_file(300000)
+    x, y, z = oracle.transform(f["pos"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    xs, ys, ms = oracle.select_project(x, y, z, None, m, ld, ld2, BOX, 0, fov, npix)
+    pix, val = npr.tsc_contributions(xs, ys, ms, npix)
+    scale = 2.0 ** (40 - (int(np.floor(np.log2(m))) + 1))  # slicer_capi.cpp pick_fixed_exp
+    q = np.rint(val.astype(np.float64) * scale).astype(np.int64)
+    acc = np.zeros(npix * npix, np.int64)
+    ok = pix >= 0
+    np.add.at(acc, pix[ok], q[ok])
+    want = (acc.astype(np.float64) / scale).astype(np.float32).reshape(npix, npix)
+    (tot, _, _), = run_gpu(S, [f], npix, fov, ld, ld2, accum=slicer_amd.ACC_FIXED64, algo=algo)
+    bad = int((tot.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, f"{bad} pixels differ from the integer sum of the restated contributions"
+
+
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
 def test_fixed64_is_bitwise_reproducible_and_linear(S, algo):
     """Order-independent accumulation: two runs agree bitwise, and a file split in two sub-files
