@@ -324,19 +324,22 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a: per bin, exclusive prefix over workgroups + total: segment sums, a 16-way scan in LDS, prefix write.
+// K2a: per bin, exclusive prefix over workgroups + total: segment sums, a 32-way scan in LDS, prefix write.
 // ---------------------------------------------------------------------------------------------
+constexpr int kScanBins = 32;               // bins per workgroup of k_scan_blocks
+constexpr int kScanSegs = 1024 / kScanBins;  // segments of the K1-workgroup axis
+
 __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__restrict__ hist16,
                                                       unsigned *__restrict__ prefix, unsigned *__restrict__ total,
                                                       int nblocks, int nbins)
 {
-    // 64 bins (one per lane: a wave reads 128 contiguous bytes of a histogram row) x 16 segments of the
-    // workgroup axis (one per wave)
-    __shared__ unsigned s_seg[16][64];
-    const int bl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int bin = blockIdx.x * 64 + bl;
+    // 32 bins (a half-wave reads 64 contiguous bytes of a histogram row) x 32 segments of the workgroup axis:
+    // 256 workgroups for 8192 bins, 16 rows per lane at 512 K1 workgroups
+    __shared__ unsigned s_seg[kScanSegs][kScanBins];
+    const int bl = threadIdx.x % kScanBins, seg = threadIdx.x / kScanBins;
+    const int bin = blockIdx.x * kScanBins + bl;
     const size_t stride16 = (size_t)((nbins + 1) >> 1) * 2;
-    const int per = (nblocks + 15) / 16;
+    const int per = (nblocks + kScanSegs - 1) / kScanSegs;
     const int lo = seg * per, hi = lo + per < nblocks ? lo + per : nblocks;
     unsigned sum = 0;
     if (bin < nbins)
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
             prefix[(size_t)b * nbins + bin] = run;
             run += v;
         }
-        if (seg == 15)
+        if (seg == kScanSegs - 1)
             total[bin] = run;
     }
 }
@@ -363,22 +366,29 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
 __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__ total, unsigned *__restrict__ base,
                                                     int nbins, int count_planes, int bins_per_plane, Targets T)
 {
-    __shared__ unsigned s_part[1024];
+    __shared__ unsigned s_part[1024], s_wave[1024 / 64];
     const int tid = threadIdx.x;
     const int per = (nbins + 1023) / 1024;
     const int lo = tid * per;
     unsigned sum = 0;
     for (int i = lo; i < lo + per && i < nbins; i++)
         sum += total[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // inclusive scan over the 1024 lanes: wave scan by shuffles + wave totals through LDS
+    unsigned x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = (unsigned)__shfl_up((int)x, d);
+        if ((int)(tid & 63) >= d)
+            x += y;
     }
-    unsigned run = tid ? s_part[tid - 1] : 0;
+    if ((tid & 63) == 63)
+        s_wave[tid >> 6] = x;
+    __syncthreads();
+    for (int k = 0; k < (tid >> 6); k++)
+        x += s_wave[k];
+    s_part[tid] = x;  // records in the bins of lanes 0..tid
+    __syncthreads();
+    unsigned run = x - sum;
     for (int i = lo; i < lo + per && i < nbins; i++) {
         base[i] = run;
         run += total[i];
@@ -848,7 +858,7 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const fl
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s)
 {
-    k_scan_blocks<<<(G.nbins + 63) / 64, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
+    k_scan_blocks<<<(G.nbins + kScanBins - 1) / kScanBins, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
                                                          nblocks, G.nbins);
     k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins, cfg.mas == kTSC ? n_planes : 0,
                                    G.units_per_plane * G.tiles_per_unit, T);
