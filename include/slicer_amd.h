@@ -164,6 +164,7 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
  * op 0: out = sqrt(a)  (unscaled Newton iteration, valid for 2^-500 <= a <= 2^500)
  * op 1: out = a / b    (same operand range; a may be 0)
  * op 2: out = asin(a)  small-angle series, |a| <= 0.3125      op 3: out = atan(a), |a| <= 0.3125
+ * op 4 / 5: the 9-term variants of 2 / 3, |a| <= 0.155
  * Lets the tests compare these with correctly rounded host results bit by bit (densitymaps.cpp:382-384 uses
  * sqrt, /, asin, atan2 of libm). */
 int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n);

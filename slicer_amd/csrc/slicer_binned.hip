@@ -133,7 +133,7 @@ __device__ __forceinline__ void load_round(const float *__restrict__ pos, const 
     }
 }
 
-template <int MAS, bool POW2, bool HAS_MASS, bool VEC>
+template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
                                                         uint64_t n, PassParams P, BinGeom G,
                                                         float2 *__restrict__ cxy, unsigned short *__restrict__ cbin,
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             if (lane < take) {
                 const float4 ent = q4[e];
                 plane = __float_as_int(ent.w);
-                if (project(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
+                if (project<SERIES>(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
                     valid = true;
                     int gx = grid_index<POW2>(xs, P);
                     int gy = grid_index<POW2>(ys, P);
@@ -814,27 +814,34 @@ size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
     return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * (has_mass ? 20 : 16);
 }
 
+template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
+static hipError_t launch_k1_2(const float *pos, const float *mass, uint64_t n, const PassParams &P, const BinGeom &G,
+                              const BinWorkspace &W, const Targets &T, hipStream_t s)
+{
+    const int nb = (int)((n + G.batch - 1) / G.batch);
+    const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
+    auto kern = k_project_bin<MAS, POW2, HAS_MASS, VEC, SERIES>;
+    if (lds > 48 * 1024) {  // up to 64 KiB of histogram + the wave stacks
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm, W.hist16,
+                                   W.bcount, T);
+    return hipGetLastError();
+}
+
 template <int MAS, bool POW2, bool HAS_MASS>
 static hipError_t launch_k1(bool vec, const float *pos, const float *mass, uint64_t n, const PassParams &P,
                             const BinGeom &G, const BinWorkspace &W, const Targets &T, hipStream_t s)
 {
-    const int nb = (int)((n + G.batch - 1) / G.batch);
-    const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
-    if (lds > 48 * 1024) {  // large maps: up to 64 KiB of histogram + 40 KiB of wave stacks
-        hipError_t e = hipFuncSetAttribute(
-            vec ? reinterpret_cast<const void *>(k_project_bin<MAS, POW2, HAS_MASS, true>)
-                : reinterpret_cast<const void *>(k_project_bin<MAS, POW2, HAS_MASS, false>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-    }
+    const bool s9 = P.series_max < 0.2;  // every survivor of the pre-test is inside the 9-term range
     if (vec)
-        k_project_bin<MAS, POW2, HAS_MASS, true><<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm,
-                                                                         W.hist16, W.bcount, T);
-    else
-        k_project_bin<MAS, POW2, HAS_MASS, false><<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm,
-                                                                          W.hist16, W.bcount, T);
-    return hipGetLastError();
+        return s9 ? launch_k1_2<MAS, POW2, HAS_MASS, true, 9>(pos, mass, n, P, G, W, T, s)
+                  : launch_k1_2<MAS, POW2, HAS_MASS, true, 15>(pos, mass, n, P, G, W, T, s);
+    return s9 ? launch_k1_2<MAS, POW2, HAS_MASS, false, 9>(pos, mass, n, P, G, W, T, s)
+              : launch_k1_2<MAS, POW2, HAS_MASS, false, 15>(pos, mass, n, P, G, W, T, s);
 }
 
 hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,

@@ -256,6 +256,10 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
         P.sin2_lim_hi = (float)(std::sin(P.lim) * std::sin(P.lim) * (1.0 + 1e-5));
     }
     P.force_libm = d.debug_flags & 1;
+    // every entry that reaches the series passed the f32 pre-test (|tan ra|, |sin dec| within 1e-5 of the limit's)
+    // or, on the direct path, may lie anywhere: there, and with debug bit 1, keep the wide 15-term range
+    P.series_max = (!(d.debug_flags & 2) && P.lim < 1.5 && std::tan(P.lim) * 1.001 < kSeriesMax9) ? kSeriesMax9
+                                                                                                   : kSeriesMax15;
     P.nn = d.npix;
     P.pow2 = is_pow2(d.npix) ? 1 : 0;
     P.dl = 1. / double(d.npix);  // utilities.cpp:50
@@ -496,6 +500,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     if (d.snopt > 0) {
         // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device,
         // draw on the host from the process-global stream (exactly what the reference consumes), deposit.
+        P.series_max = kSeriesMax15;  // no pre-test on this path either
         const uint64_t nchunks = (n + 63) / 64;
         int rc;
         if ((rc = ensure(h, h->w_tcounts, nchunks * 4)) || (rc = ensure(h, h->w_tbase, (nchunks + 1) * 8)))
@@ -532,6 +537,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         binned = false;  // several launches are not worth it for a tiny chunk
     if (!binned) {
         ProfScope ps(h, KN_DIRECT);
+        P.series_max = kSeriesMax15;  // no pre-test on this path: entries far outside the field reach project()
         HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
         return SLICER_OK;
     }
@@ -1154,7 +1160,7 @@ int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *
 {
     if (!h)
         return fail(h, SLICER_ERR_ARG, "null handle");
-    if (op < 0 || op > 3 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
+    if (op < 0 || op > 5 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
         return fail(h, SLICER_ERR_ARG, "slicer_debug_math: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, launch_debug_math(op, d_a, d_b, d_out, n, h->stream));

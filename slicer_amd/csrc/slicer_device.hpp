@@ -41,7 +41,8 @@ struct PassParams {
     double inv_fov;  // RN(1/fov): fast path of to_map_coord()
     double lim;      // fov * (1. + 2. / npix) * 0.5
     float tan_lim_hi, sin2_lim_hi;  // tan(lim) and sin^2(lim), inflated by 1e-5: surely_outside_fov()
-    int force_libm;  // debug: always use OCML asin/atan2
+    int force_libm;  // debug: bit 0 always use OCML asin/atan2, bit 1 always the 15-term series
+    double series_max;  // largest |sin dec|, |tan ra| the series path takes: kSeriesMax9 or kSeriesMax15
     // --- grid (utilities.cpp:50,69-70) ---
     int nn;
     int pow2;        // nn is a power of two: x / dl == x * nn exactly
@@ -132,18 +133,30 @@ __device__ __forceinline__ double fma_sc(double r, double w, double c)
     return o;
 }
 
+// N = 15 terms serve |x| <= 0.3125; N = 9 terms serve |x| <= 0.155 (fields of view up to ~17 deg) with the same
+// truncation bound (A10 z^10 and z^10 / 21 are below 0.03 ulp there) and six fewer dependent fp64 FMAs per series.
+constexpr double kSeriesMax15 = 0.3125, kSeriesMax9 = 0.155;
+
+template <int N>
 __device__ __forceinline__ double asin_small(double x)
 {
+    static_assert(N == 9 || N == 15, "term counts with a proven range");
     const double z = x * x, w = z * z;
-    // A1..A15 split: even-index chain (A1, A3, ..., A15) and odd-index chain (A2, A4, ..., A14)
-    double pe = fma_sc(0x1.31683bdef7bdfp-8, w, 0x1.782dda12f684cp-8);  // A15, A13
-    double po = fma_sc(0x1.51ba308d3dcb1p-8, w, 0x1.a6863d70a3d71p-8);  // A14, A12
-    pe = fma_sc(pe, w, 0x1.df3bd37a6f4dfp-8);         // A11
-    po = fma_sc(po, w, 0x1.12ef3cf3cf3cfp-7);         // A10
-    pe = fma_sc(pe, w, 0x1.3fde50d79435ep-7);         // A9
-    po = fma_sc(po, w, 0x1.7a87878787878p-7);         // A8
-    pe = fma_sc(pe, w, 0x1.c99999999999ap-7);         // A7
-    po = fma_sc(po, w, 0x1.1c4ec4ec4ec4fp-6);         // A6
+    // A1..AN split: even-index chain (A1, A3, ..., AN) and odd-index chain (A2, A4, ..., A(N-1))
+    double pe, po;
+    if (N == 15) {
+        pe = fma_sc(0x1.31683bdef7bdfp-8, w, 0x1.782dda12f684cp-8);  // A15, A13
+        po = fma_sc(0x1.51ba308d3dcb1p-8, w, 0x1.a6863d70a3d71p-8);  // A14, A12
+        pe = fma_sc(pe, w, 0x1.df3bd37a6f4dfp-8);     // A11
+        po = fma_sc(po, w, 0x1.12ef3cf3cf3cfp-7);     // A10
+        pe = fma_sc(pe, w, 0x1.3fde50d79435ep-7);     // A9
+        po = fma_sc(po, w, 0x1.7a87878787878p-7);     // A8
+        pe = fma_sc(pe, w, 0x1.c99999999999ap-7);     // A7
+        po = fma_sc(po, w, 0x1.1c4ec4ec4ec4fp-6);     // A6
+    } else {
+        pe = fma_sc(0x1.3fde50d79435ep-7, w, 0x1.c99999999999ap-7);  // A9, A7
+        po = fma_sc(0x1.7a87878787878p-7, w, 0x1.1c4ec4ec4ec4fp-6);  // A8, A6
+    }
     pe = fma_sc(pe, w, 0x1.6e8ba2e8ba2e9p-6);         // A5
     po = fma_sc(po, w, 0x1.f1c71c71c71c7p-6);         // A4
     pe = fma_sc(pe, w, 0x1.6db6db6db6db7p-5);         // A3
@@ -153,17 +166,25 @@ __device__ __forceinline__ double asin_small(double x)
     return fma(x * z, p, x);
 }
 
+template <int N>
 __device__ __forceinline__ double atan_small(double t)
 {
+    static_assert(N == 9 || N == 15, "term counts with a proven range");
     const double z = t * t, w = z * z;
-    double pe = fma_sc(-0x1.0842108421084p-5, w, -0x1.2f684bda12f68p-5);  // -1/31, -1/27
-    double po = fma_sc(0x1.1a7b9611a7b96p-5, w, 0x1.47ae147ae147bp-5);    // +1/29, +1/25
-    pe = fma_sc(pe, w, -0x1.642c8590b2164p-5);        // -1/23
-    po = fma_sc(po, w, 0x1.8618618618618p-5);         // +1/21
-    pe = fma_sc(pe, w, -0x1.af286bca1af28p-5);        // -1/19
-    po = fma_sc(po, w, 0x1.e1e1e1e1e1e1ep-5);         // +1/17
-    pe = fma_sc(pe, w, -0x1.1111111111111p-4);        // -1/15
-    po = fma_sc(po, w, 0x1.3b13b13b13b14p-4);         // +1/13
+    double pe, po;
+    if (N == 15) {
+        pe = fma_sc(-0x1.0842108421084p-5, w, -0x1.2f684bda12f68p-5);  // -1/31, -1/27
+        po = fma_sc(0x1.1a7b9611a7b96p-5, w, 0x1.47ae147ae147bp-5);    // +1/29, +1/25
+        pe = fma_sc(pe, w, -0x1.642c8590b2164p-5);    // -1/23
+        po = fma_sc(po, w, 0x1.8618618618618p-5);     // +1/21
+        pe = fma_sc(pe, w, -0x1.af286bca1af28p-5);    // -1/19
+        po = fma_sc(po, w, 0x1.e1e1e1e1e1e1ep-5);     // +1/17
+        pe = fma_sc(pe, w, -0x1.1111111111111p-4);    // -1/15
+        po = fma_sc(po, w, 0x1.3b13b13b13b14p-4);     // +1/13
+    } else {
+        pe = fma_sc(-0x1.af286bca1af28p-5, w, -0x1.1111111111111p-4);  // -1/19, -1/15
+        po = fma_sc(0x1.e1e1e1e1e1e1ep-5, w, 0x1.3b13b13b13b14p-4);    // +1/17, +1/13
+    }
     pe = fma_sc(pe, w, -0x1.745d1745d1746p-4);        // -1/11
     po = fma_sc(po, w, 0x1.c71c71c71c71cp-4);         // +1/9
     pe = fma_sc(pe, w, -0x1.2492492492492p-3);        // -1/7
@@ -239,6 +260,9 @@ __device__ SLICER_SLOWPATH Polar polar_exact(double X, double Y, double Z)
     return r;
 }
 
+// SERIES: terms of the small-angle series compiled in (9 or 15); 0 = chosen at run time from P.series_max (costs
+// registers: both variants are live code).  The hot kernel is instantiated for 9 and 15 and picked at launch.
+template <int SERIES = 0>
 __device__ __forceinline__ bool project(float x, float y, float z, int ni, int nj, const PassParams &P, float &xs,
                                         float &ys)
 {
@@ -253,9 +277,17 @@ __device__ __forceinline__ bool project(float x, float y, float z, int ni, int n
     const double d = sqrt_midrange(S);
     const double q = div_midrange(X, d);
     double dec, ra;
-    if (mid && fabs(q) <= 0.3125 && fabs(Y) <= 0.3125 * Z && !(P.force_libm & 1)) {
-        dec = asin_small(q);
-        ra = atan_small(div_midrange(Y, Z));
+    // P.series_max: 0.155 with 9-term series when the field of view (plus the pre-test's margin) stays below it,
+    // else 0.3125 with 15 terms; wave-uniform choice
+    if (mid && fabs(q) <= P.series_max && fabs(Y) <= P.series_max * Z && !(P.force_libm & 1)) {
+        const double t = div_midrange(Y, Z);
+        if (SERIES == 9 || (SERIES == 0 && P.series_max < 0.2)) {
+            dec = asin_small<9>(q);
+            ra = atan_small<9>(t);
+        } else {
+            dec = asin_small<15>(q);
+            ra = atan_small<15>(t);
+        }
     } else {
         const Polar pl = polar_exact(X, Y, Z);
         dec = pl.dec;

@@ -513,8 +513,10 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
     switch (op) {
     case 0: r = sqrt_midrange(a[i]); break;
     case 1: r = div_midrange(a[i], b[i]); break;
-    case 2: r = asin_small(a[i]); break;
-    default: r = atan_small(a[i]); break;
+    case 2: r = asin_small<15>(a[i]); break;
+    case 3: r = atan_small<15>(a[i]); break;
+    case 4: r = asin_small<9>(a[i]); break;
+    default: r = atan_small<9>(a[i]); break;
     }
     out[i] = r;
 }

@@ -152,15 +152,16 @@ def test_project_bits_large_sample(S):
     assert bad == 0, f"{bad} of {2 * cnt} coordinates differ in the last bit"
 
 
-def test_small_angle_series_equals_libm_path(S):
-    """The 15-term asin/atan series (|x| <= 0.3125) against OCML's asin/atan2 on the device: the f32 map
-    coordinates of 2^23 particles must agree bit for bit (both are <= ~1 ulp(f64) routines)."""
+@pytest.mark.parametrize("fov", [0.5, 0.25])
+def test_small_angle_series_equals_libm_path(S, fov):
+    """The asin/atan series (15 terms at fov 0.5, 9 terms at fov 0.25) against OCML's asin/atan2 on the device: the
+    f32 map coordinates of 2^23 particles must agree bit for bit (both are <= ~1 ulp(f64) routines)."""
     n = 1 << 23
     d = S.malloc(12 * n)
     S.synth_positions(d, 0, n, BOX, seed=77)
     outs = []
     for flags in (0, 1):
-        S.plane_begin(4096, 0.5, [3.0], [4.0], debug_flags=flags)
+        S.plane_begin(4096, fov, [3.0], [4.0], debug_flags=flags)
         S.file_begin([0, n, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
         cnt, xs, ys, pl, src = S.debug_project(1, d, n, n)
         S.file_end()
@@ -222,15 +223,19 @@ def test_device_quotient_is_correctly_rounded(S):
 
 
 def test_device_series_accuracy(S):
-    """asin_small / atan_small against numpy's libm in float64 on |x| <= 0.3125: at most 1 ulp apart (both sides are
+    """asin_small / atan_small (15 terms on |x| <= 0.3125, 9 terms on |x| <= 0.155) against numpy's libm in float64: at most 1 ulp apart (both sides are
     ~1 ulp routines; the f32 map coordinate absorbs this, see test_small_angle_series_equals_libm_path)."""
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-0.3125, 0.3125, 1 << 20), [0.0, 0.3125, -0.3125, 1e-300, 2.0 ** -30]])
-    for op, fn in ((2, np.arcsin), (3, np.arctan)):
-        got, want = S.debug_math(op, x), fn(x)
+    x9 = np.concatenate([rng.uniform(-0.155, 0.155, 1 << 20), [0.0, 0.155, -0.155, 1e-300, 2.0 ** -30]])
+    for op, fn, arg in ((2, np.arcsin, x), (3, np.arctan, x), (4, np.arcsin, x9), (5, np.arctan, x9)):
+        got, want = S.debug_math(op, arg), fn(arg)
         ulp = np.abs(got - want) / np.spacing(np.abs(want))
         assert ulp.max() <= 1.0, (op, ulp.max())
         assert (ulp == 0).mean() > 0.9
+    # the 9-term and 15-term variants agree to the last bit almost everywhere on the 9-term range
+    for a, b in ((2, 4), (3, 5)):
+        assert (S.debug_math(a, x9).view(np.uint64) != S.debug_math(b, x9).view(np.uint64)).mean() < 0.02
 
 
 def test_large_fov_uses_libm_path(S):
