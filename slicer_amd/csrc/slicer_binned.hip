@@ -366,47 +366,59 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
 __global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__ total, unsigned *__restrict__ base,
                                                     int nbins, int count_planes, int bins_per_plane, Targets T)
 {
-    __shared__ unsigned s_part[1024], s_wave[1024 / 64];
+    // a lane owns kScanPer consecutive bins of each 1024 * kScanPer-bin slab; its loads are issued together
+    // (a loop of dependent load -> add round trips made this single-workgroup kernel latency-bound)
+    constexpr int kScanPer = 8;
+    __shared__ unsigned s_wave[1024 / 64], s_pre[kMaxPlanes + 1];
+    __shared__ unsigned s_carry;
     const int tid = threadIdx.x;
-    const int per = (nbins + 1023) / 1024;
-    const int lo = tid * per;
-    unsigned sum = 0;
-    for (int i = lo; i < lo + per && i < nbins; i++)
-        sum += total[i];
-    // inclusive scan over the 1024 lanes: wave scan by shuffles + wave totals through LDS
-    unsigned x = sum;
+    if (tid == 0)
+        s_carry = 0;
+    __syncthreads();
+    for (int slab = 0; slab < nbins; slab += 1024 * kScanPer) {
+        const int lo = slab + tid * kScanPer;
+        unsigned v[kScanPer];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned y = (unsigned)__shfl_up((int)x, d);
-        if ((int)(tid & 63) >= d)
-            x += y;
-    }
-    if ((tid & 63) == 63)
-        s_wave[tid >> 6] = x;
-    __syncthreads();
-    for (int k = 0; k < (tid >> 6); k++)
-        x += s_wave[k];
-    s_part[tid] = x;  // records in the bins of lanes 0..tid
-    __syncthreads();
-    unsigned run = x - sum;
-    for (int i = lo; i < lo + per && i < nbins; i++) {
-        base[i] = run;
-        run += total[i];
-    }
-    if (tid == 1023)
-        base[nbins] = s_part[1023];
-    if (tid < count_planes) {
-        // prefix(b) = records in bins [0, b): whole threads from s_part, the rest of thread b / per from total[]
-        unsigned pre[2];
-        for (int e = 0; e < 2; e++) {
-            const int b = (tid + e) * bins_per_plane, t = b / per;
-            unsigned v = t ? s_part[t - 1] : 0;
-            for (int i = t * per; i < b; i++)
-                v += total[i];
-            pre[e] = v;
+        for (int j = 0; j < kScanPer; j++)
+            v[j] = lo + j < nbins ? total[lo + j] : 0u;
+        unsigned sum = 0;
+#pragma unroll
+        for (int j = 0; j < kScanPer; j++)
+            sum += v[j];
+        unsigned x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, d);
+            if ((int)(tid & 63) >= d)
+                x += y;
         }
-        if (pre[1] != pre[0])
-            atomicAdd(T.nsel[tid], (unsigned long long)(pre[1] - pre[0]));
+        if ((tid & 63) == 63)
+            s_wave[tid >> 6] = x;
+        __syncthreads();
+        unsigned run = s_carry + x - sum;
+        for (int k = 0; k < (tid >> 6); k++)
+            run += s_wave[k];
+#pragma unroll
+        for (int j = 0; j < kScanPer; j++) {
+            const int i = lo + j;
+            if (i < nbins) {
+                base[i] = run;
+                if (count_planes && i % bins_per_plane == 0)
+                    s_pre[i / bins_per_plane] = run;  // records before the first bin of a plane
+            }
+            run += v[j];
+        }
+        __syncthreads();
+        if (tid == 1023)
+            s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0)
+        base[nbins] = s_carry;
+    if (tid < count_planes) {
+        const unsigned c = (tid + 1 < count_planes ? s_pre[tid + 1] : s_carry) - s_pre[tid];
+        if (c)
+            atomicAdd(T.nsel[tid], (unsigned long long)c);
     }
 }
 
@@ -632,47 +644,66 @@ struct TileItems {
 
 __global__ __launch_bounds__(1024) void k_build_items(PendingList L, int nbins, TileItems I)
 {
+    // a lane owns kPer consecutive bins of each 1024 * kPer-bin slab; the run lengths of every pending chunk are read
+    // with independent loads (kPer + 1 boundaries per chunk)
+    constexpr int kPer = 8;
     __shared__ unsigned s_wave[1024 / 64];
+    __shared__ unsigned s_carry;
     const int tid = threadIdx.x;
-    const int per = (nbins + 1023) / 1024;
-    unsigned mine = 0;
-    for (int j = 0; j < per; j++) {
-        const int b = tid * per + j;
-        if (b < nbins) {
-            unsigned tot = 0;
-            for (int c = 0; c < L.n; c++)
-                tot += L.base[c][b + 1] - L.base[c][b];
-            const unsigned np = (tot + kItemRecs - 1) / kItemRecs;
-            I.nparts[b] = np;
-            mine += np;
-        }
-    }
-    // exclusive scan over the 1024 lanes (wave scan + wave totals through LDS)
-    unsigned x = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned y = (unsigned)__shfl_up((int)x, d);
-        if ((int)(threadIdx.x & 63) >= d)
-            x += y;
-    }
-    if ((threadIdx.x & 63) == 63)
-        s_wave[tid >> 6] = x;
+    if (tid == 0)
+        s_carry = 0;
     __syncthreads();
-    unsigned off = 0;
-    for (int k = 0; k < (tid >> 6); k++)
-        off += s_wave[k];
-    unsigned e = off + x - mine;
-    for (int j = 0; j < per; j++) {
-        const int b = tid * per + j;
-        if (b < nbins) {
-            const unsigned np = I.nparts[b];
-            for (unsigned q = 0; q < np; q++)
-                I.items[e + q] = make_uint2((unsigned)b, q);
-            e += np;
+    for (int slab = 0; slab < nbins; slab += 1024 * kPer) {
+        const int lo = slab + tid * kPer;
+        unsigned tot[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; j++)
+            tot[j] = 0;
+        for (int c = 0; c < L.n; c++) {
+            unsigned e[kPer + 1];
+#pragma unroll
+            for (int j = 0; j <= kPer; j++)
+                e[j] = lo + j <= nbins ? L.base[c][lo + j] : 0u;
+#pragma unroll
+            for (int j = 0; j < kPer; j++)
+                if (lo + j < nbins)
+                    tot[j] += e[j + 1] - e[j];
         }
+        unsigned np[kPer], mine = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            np[j] = lo + j < nbins ? (tot[j] + kItemRecs - 1) / kItemRecs : 0u;
+            if (lo + j < nbins)
+                I.nparts[lo + j] = np[j];
+            mine += np[j];
+        }
+        // exclusive scan over the 1024 lanes (wave scan + wave totals through LDS)
+        unsigned x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, d);
+            if ((int)(tid & 63) >= d)
+                x += y;
+        }
+        if ((tid & 63) == 63)
+            s_wave[tid >> 6] = x;
+        __syncthreads();
+        unsigned e0 = s_carry + x - mine;
+        for (int k = 0; k < (tid >> 6); k++)
+            e0 += s_wave[k];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            for (unsigned q = 0; q < np[j]; q++)
+                I.items[e0 + q] = make_uint2((unsigned)(lo + j), q);
+            e0 += np[j];
+        }
+        __syncthreads();
+        if (tid == 1023)
+            s_carry = e0;
+        __syncthreads();
     }
-    if (tid == 1023)
-        *I.n_items = e;
+    if (tid == 0)
+        *I.n_items = s_carry;
 }
 
 constexpr int kTileBlock = 1024;
