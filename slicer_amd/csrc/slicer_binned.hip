@@ -257,30 +257,16 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             }
             top -= take;
             // selected-entry counters.  TSC emits every selected entry, so k_scan_bins takes them from the bin totals;
-            // NGP drops off-grid entries after selection and counts here: one LDS add per wave and plane
-            if (MAS == kNGP) {
-                for (int p = 0; p < P.n_planes; p++) {
-                    const unsigned c = (unsigned)__popcll(__ballot(valid && plane == p));
-                    if (c && lane == 0)
-                        atomicAdd(&s_cnt[p], c);
-                }
-            }
+            // NGP drops off-grid entries after selection and counts here: one LDS add per lane (the LDS pipe has slack)
+            if (MAS == kNGP && valid)
+                atomicAdd(&s_cnt[plane], 1u);
             // Records go to the compact region of (unit, workgroup): [ (unit*gridDim.x + blockIdx.x) * batch, ... ).
-            // One reservation per wave and distinct unit (a single returning LDS add by that unit's first lane).
             unsigned o = 0;
-            unsigned long long todo = __ballot(emit);
-            while (todo != 0ull) {
-                const int leader = __ffsll((long long)todo) - 1;  // wave-uniform: broadcasts are v_readlane
-                const unsigned u = (unsigned)__builtin_amdgcn_readlane((int)unit, leader);
-                const unsigned long long me = __ballot(emit && unit == u);
-                unsigned base = 0;
-                if ((int)lane == leader)
-                    base = atomicAdd(&s_out[u], (unsigned)__popcll(me));
-                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-                if (emit && unit == u)
-                    o = base + (unsigned)__popcll(me & ((1ull << lane) - 1ull));
-                todo &= ~me;
-            }
+            // One returning LDS add per lane.  The LDS pipe serialises the lanes that share a unit, but it has slack
+            // in this kernel, while a loop over the wave's distinct units (one add by a leader lane, broadcasts, rank
+            // from ballots) cost the VALU -- the kernel's bound -- and a chain of LDS round trips: 175 -> 149 us.
+            if (emit)
+                o = atomicAdd(&s_out[unit], 1u);
             if (emit) {
                 const uint64_t dst = ((uint64_t)unit * gridDim.x + blockIdx.x) * (uint64_t)G.batch + o;
                 cxy[dst] = make_float2(xs, ys);
