@@ -38,7 +38,7 @@ struct PassParams {
     int nrep[kMaxPlanes];
     // --- projection (densitymaps.cpp:382-386) ---
     double fov;
-    double inv_fov;  // RN(1/fov): fast path of to_map_coord()
+    double inv_fov;  // RN(1/fov): fast path of the map coordinate, see map_coord_risky()
     double lim;      // fov * (1. + 2. / npix) * 0.5
     float tan_lim_hi, sin2_lim_hi;  // tan(lim) and sin^2(lim), inflated by 1e-5: surely_outside_fov()
     int force_libm;  // debug: bit 0 always use OCML asin/atan2, bit 1 always the 15-term series
@@ -226,21 +226,24 @@ __device__ __forceinline__ double div_midrange(double n, double d)  // 2^-500 <=
 }
 
 // (float)(ang / fov + 0.5)      densitymaps.cpp:385-386
-// RN64(ang * RN64(1/fov)) + 0.5 is within 2^-51 (absolute, |ang/fov| < 1) of the reference's f64 value, so
-// its rounding to f32 is the reference's unless it sits that close to an f32 tie; those cases, and values
-// that are not in (2^-27, 1], take the exact division.
-__device__ __forceinline__ float to_map_coord(double ang, const PassParams &P)
+// s = RN64(ang * RN64(1/fov)) + 0.5 is within 2^-51 (absolute, |ang/fov| < 1) of the reference's f64 value, so its
+// rounding to f32 is the reference's unless s sits within 2^-50 of an f32 rounding tie.  The test is made cheap rather
+// than tight: for 2^-13 <= s < 2 one ulp(f64) of s is >= 2^-65, so "bits 28..0 of the mantissa within 2^15 of the tie
+// pattern" covers 2^-50 everywhere in that range (p = 1.2e-4 per coordinate); values outside the range (the leftmost
+// 0.01 % of the map, negative values) are treated as risky too.  Risky lanes take the exact division, out of line and
+// behind one wave-uniform branch for both coordinates.
+__device__ __forceinline__ bool map_coord_risky(double s)
 {
-    double s = ang * P.inv_fov + 0.5;
     const unsigned long long b = (unsigned long long)__double_as_longlong(s);
-    const unsigned ex = (unsigned)(b >> 52) & 0xFFFu;  // sign + exponent: negative values fail the range test
-    const unsigned lo = (unsigned)b & 0x1FFFFFFFu;
-    const unsigned dist = lo > 0x10000000u ? lo - 0x10000000u : 0x10000000u - lo;
-    const bool in_range = ex >= 1023u - 27u && ex <= 1023u;
-    const unsigned sh = 1025u - ex;  // 2^(2-e) ulps of s  >=  2^-50 absolute
-    if (!in_range || dist <= (1u << (sh > 28u ? 28u : sh)))
-        s = ang / P.fov + 0.5;
-    return (float)s;
+    const unsigned hi = (unsigned)(b >> 32), lo = (unsigned)b & 0x1FFFFFFFu;
+    const bool near_tie = __usad(lo, 0x10000000u, 0u) <= (1u << 15);           // v_sad_u32
+    const bool in_range = (hi - 0x3F200000u) <= (0x3FFFFFFFu - 0x3F200000u);   // 2^-13 <= s < 2
+    return near_tie || !in_range;
+}
+
+__device__ SLICER_SLOWPATH double map_coord_exact(double ang, double fov, double s)
+{
+    return map_coord_risky(s) ? ang / fov + 0.5 : s;
 }
 
 // A3: getPolar(radec) + FOV test + map coordinates.   densitymaps.cpp:382-386, utilities.cpp:23-25
@@ -295,8 +298,13 @@ __device__ __forceinline__ bool project(float x, float y, float z, int ni, int n
     }
     if (!(fabs(ra) <= P.lim && fabs(dec) <= P.lim))
         return false;  // NaN (d == 0) is rejected, as in the reference
-    xs = to_map_coord(dec, P);
-    ys = to_map_coord(ra, P);
+    double sx = dec * P.inv_fov + 0.5, sy = ra * P.inv_fov + 0.5;
+    if (__ballot(map_coord_risky(sx) || map_coord_risky(sy)) != 0ull) {
+        sx = map_coord_exact(dec, P.fov, sx);
+        sy = map_coord_exact(ra, P.fov, sy);
+    }
+    xs = (float)sx;
+    ys = (float)sy;
     return true;
 }
 
