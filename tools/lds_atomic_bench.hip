@@ -26,9 +26,23 @@ __global__ __launch_bounds__(512) void k(T *out, int iters)
             for (int b = -1; b <= 1; b++)
 #pragma unroll
                 for (int a = -1; a <= 1; a++) tile[(cy + b) * 130 + cx + a] = (T)it;
-        } else {  // 9 atomics to lane-private (conflict-free) cells
+        } else if (MODE == 2) {  // 9 atomics to lane-private (conflict-free) cells
 #pragma unroll
             for (int j = 0; j < 9; j++) atomicAdd(&tile[(threadIdx.x + 512 * j) % cells], (T)1);
+        } else {  // MODE 3 / 4: nine lanes per record (7 records per wave), one atomic per lane and record; row pitch
+                  // 130 (MODE 3) or 131 (MODE 4: the three rows of a record fall on disjoint banks)
+            const int pitch = MODE == 3 ? 130 : 131;
+            const unsigned lane = threadIdx.x & 63u, rec = lane / 9u, cell = lane % 9u;
+#pragma unroll
+            for (int j = 0; j < 9; j++) {  // same number of lane-ops per iteration as MODE 0 (lane 63 idles)
+                unsigned r = (threadIdx.x & ~63u) * 2654435761u + rec * 97u + blockIdx.x * 40503u + it * 9u + j;
+                r = r * 1664525u + 1013904223u;
+                r ^= r >> 15;
+                r *= 2246822519u;
+                const unsigned cx = 1 + ((r >> 8) & 127), cy = 1 + ((r >> 20) & 63);
+                if (lane < 63)
+                    atomicAdd(&tile[(cy + cell / 3 - 1) * pitch + cx + cell % 3 - 1], (T)1);
+            }
         }
     }
     __syncthreads();
@@ -72,5 +86,9 @@ int main()
     run<float, 2>("ds_add_f32 conflict-free");
     run<unsigned, 2>("ds_add_u32 conflict-free");
     run<unsigned long long, 2>("ds_add_u64 conflict-free");
+    run<double, 2>("ds_add_f64 conflict-free");
+    run<double, 3>("ds_add_f64 9 lanes/rec p130");
+    run<double, 4>("ds_add_f64 9 lanes/rec p131");
+    run<unsigned long long, 4>("ds_add_u64 9 lanes/rec p131");
     return 0;
 }
