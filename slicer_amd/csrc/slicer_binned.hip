@@ -623,73 +623,32 @@ __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, 
 constexpr unsigned kItemRecs = 16384;
 
 struct TileItems {
-    uint2 *items;      // [max_items] {bin, part}
-    unsigned *nparts;  // [nbins]
-    unsigned *n_items; // [1]
+    unsigned *nparts;   // [nbins] parts of every bin (0 = empty: no work item)
+    uint2 *extra;       // {bin, part} of the parts >= 1 of heavy bins, in no particular order
+    unsigned *n_extra;  // entries of extra[]: zero before k_build_items, which also zeroes next_n_extra
+    unsigned *next_n_extra;
 };
 
-__global__ __launch_bounds__(1024) void k_build_items(PendingList L, int nbins, TileItems I)
+// Work items of the tile kernel: part 0 of bin b is workgroup b; the further parts of heavy bins are appended to a
+// list with one atomic add per heavy bin (their order does not matter), so that the builder is a plain parallel
+// kernel instead of a single-workgroup scan.
+__global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, TileItems I)
 {
-    // a lane owns kPer consecutive bins of each 1024 * kPer-bin slab; the run lengths of every pending chunk are read
-    // with independent loads (kPer + 1 boundaries per chunk)
-    constexpr int kPer = 8;
-    __shared__ unsigned s_wave[1024 / 64];
-    __shared__ unsigned s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0)
-        s_carry = 0;
-    __syncthreads();
-    for (int slab = 0; slab < nbins; slab += 1024 * kPer) {
-        const int lo = slab + tid * kPer;
-        unsigned tot[kPer];
-#pragma unroll
-        for (int j = 0; j < kPer; j++)
-            tot[j] = 0;
-        for (int c = 0; c < L.n; c++) {
-            unsigned e[kPer + 1];
-#pragma unroll
-            for (int j = 0; j <= kPer; j++)
-                e[j] = lo + j <= nbins ? L.base[c][lo + j] : 0u;
-#pragma unroll
-            for (int j = 0; j < kPer; j++)
-                if (lo + j < nbins)
-                    tot[j] += e[j + 1] - e[j];
-        }
-        unsigned np[kPer], mine = 0;
-#pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            np[j] = lo + j < nbins ? (tot[j] + kItemRecs - 1) / kItemRecs : 0u;
-            if (lo + j < nbins)
-                I.nparts[lo + j] = np[j];
-            mine += np[j];
-        }
-        // exclusive scan over the 1024 lanes (wave scan + wave totals through LDS)
-        unsigned x = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned y = (unsigned)__shfl_up((int)x, d);
-            if ((int)(tid & 63) >= d)
-                x += y;
-        }
-        if ((tid & 63) == 63)
-            s_wave[tid >> 6] = x;
-        __syncthreads();
-        unsigned e0 = s_carry + x - mine;
-        for (int k = 0; k < (tid >> 6); k++)
-            e0 += s_wave[k];
-#pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            for (unsigned q = 0; q < np[j]; q++)
-                I.items[e0 + q] = make_uint2((unsigned)(lo + j), q);
-            e0 += np[j];
-        }
-        __syncthreads();
-        if (tid == 1023)
-            s_carry = e0;
-        __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b == 0)
+        *I.next_n_extra = 0;  // the counter of the next launch (stream order makes this safe)
+    if (b >= nbins)
+        return;
+    unsigned tot = 0;
+    for (int c = 0; c < L.n; c++)
+        tot += L.base[c][b + 1] - L.base[c][b];
+    const unsigned np = (tot + kItemRecs - 1) / kItemRecs;
+    I.nparts[b] = np;
+    if (np > 1) {
+        const unsigned at = atomicAdd(I.n_extra, np - 1);
+        for (unsigned q = 1; q < np; q++)
+            I.extra[at + q - 1] = make_uint2((unsigned)b, q);
     }
-    if (tid == 0)
-        *I.n_items = s_carry;
 }
 
 constexpr int kTileBlock = 1024;
@@ -782,10 +741,17 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     extern __shared__ unsigned char smem_raw[];
     lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
 
-    if (blockIdx.x >= *I.n_items)
+    unsigned bin = blockIdx.x, part = 0;
+    if (blockIdx.x >= (unsigned)G.nbins) {
+        const unsigned j = blockIdx.x - (unsigned)G.nbins;
+        if (j >= *I.n_extra)
+            return;
+        const uint2 item = I.extra[j];
+        bin = item.x, part = item.y;
+    }
+    const unsigned nparts = I.nparts[bin];
+    if (nparts == 0)
         return;
-    const uint2 item = I.items[blockIdx.x];
-    const unsigned bin = item.x, part = item.y, nparts = I.nparts[bin];
     const int unit = bin / G.tiles_per_unit;
     const int t = bin % G.tiles_per_unit;
     const int plane = unit / G.units_per_plane;
@@ -954,20 +920,23 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
 
 size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles)
 {
-    const uint64_t max_items = (uint64_t)G.nbins + total_particles / kItemRecs + 1;
-    return max_items * sizeof(uint2) + (size_t)G.nbins * 4 + 16;
+    const uint64_t max_extra = total_particles / kItemRecs + 1;
+    return 16 + (size_t)(G.nbins + (G.nbins & 1)) * 4 + max_extra * sizeof(uint2);  // counters | nparts | extra
 }
 
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
-                               const Targets &T, void *items_ws, uint64_t total_particles, hipStream_t s)
+                               const Targets &T, void *items_ws, unsigned epoch, uint64_t total_particles, hipStream_t s)
 {
-    // total_particles bounds the number of records (each particle emits at most one on this path)
+    // total_particles bounds the number of records (each particle emits at most one on this path).  Workspace:
+    // two counters (used alternately: launch `epoch` reads [epoch & 1] and zeroes the other one) | nparts | extra
     const unsigned max_items = (unsigned)((uint64_t)G.nbins + total_particles / kItemRecs + 1);
     TileItems I;
-    I.items = reinterpret_cast<uint2 *>(items_ws);
-    I.nparts = reinterpret_cast<unsigned *>(I.items + max_items);
-    I.n_items = I.nparts + G.nbins;
-    k_build_items<<<1, 1024, 0, s>>>(L, G.nbins, I);
+    unsigned *counters = reinterpret_cast<unsigned *>(items_ws);
+    I.n_extra = counters + (epoch & 1u);
+    I.next_n_extra = counters + ((epoch + 1u) & 1u);
+    I.nparts = counters + 4;
+    I.extra = reinterpret_cast<uint2 *>(I.nparts + G.nbins + (G.nbins & 1));
+    k_build_items<<<(G.nbins + 255) / 256, 256, 0, s>>>(L, G.nbins, I);
     const bool pow2 = P.pow2 != 0;
     if (cfg.mas == kNGP) {
         if (cfg.acc == kCountU32)

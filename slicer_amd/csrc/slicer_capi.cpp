@@ -45,6 +45,7 @@ enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SC
 struct slicer_handle_s {
     int device = 0;
     int num_cus = 256;
+    unsigned items_epoch = 0;  // launches of the tile kernel on the current w_items workspace
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipStream_t own = nullptr;
@@ -474,13 +475,18 @@ int flush_pending(slicer_handle h)
 {
     if (h->pend.n == 0)
         return SLICER_OK;
+    const void *before = h->w_items.p;
     int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles));
     if (rc)
         return rc;
+    if (h->w_items.p != before) {  // fresh workspace: both work-item counters start at zero
+        HIPCHK(h, hipMemsetAsync(h->w_items.p, 0, 16, h->stream));
+        h->items_epoch = 0;
+    }
     {
         ProfScope ps(h, KN_TILE);
         HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, h->w_items.p,
-                                      h->pend_particles, h->stream));
+                                      h->items_epoch++, h->pend_particles, h->stream));
     }
     h->pend.n = 0;
     h->pend_key = -1;

@@ -116,6 +116,6 @@ struct PendingList {
 };
 size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles);
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
-                               const Targets &T, void *items_ws, uint64_t total_particles, hipStream_t s);
+                               const Targets &T, void *items_ws, unsigned epoch, uint64_t total_particles, hipStream_t s);
 
 }  // namespace slicer
