@@ -11,10 +11,12 @@
 //                        on the data path.
 //   K2 k_scan_blocks / k_scan_bins : exclusive prefix over (bin-major, block-minor) -> every block's
 //                        write cursor for every bin (radix-partition style; no atomics).
-//   K3 k_bin_scatter   : moves each record to its bin's contiguous run (LDS cursors).
-//   K4 k_tile_deposit  : one workgroup per (plane, tile): tile + 1-pixel halo privatised in LDS,
-//                        ds_add_{f32,f64,u64,u32} per contribution, then one shaped (row-contiguous)
-//                        global atomic flush of the non-zero cells.
+//   K3 k_bin_scatter   : moves each record to its bin's contiguous run: persistent workgroups counting-sort
+//                        the records of one (plane, K1 workgroup) region by tile in LDS and store them in
+//                        tile order (coalesced runs).
+//   K4 k_tile_deposit  : one workgroup per (plane, tile) (more for heavy tiles): tile + 1-pixel halo
+//                        privatised in LDS as 8-byte cells, ds_add_{f64,u64,u32} per contribution, then one
+//                        shaped (row-contiguous) global atomic flush of the non-zero cells.
 //
 // Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
 #include "slicer_kernels.hpp"
@@ -31,7 +33,7 @@ namespace {
 #ifndef SLICER_K1_WAVES_PER_SIMD
 #define SLICER_K1_WAVES_PER_SIMD 6
 #endif
-constexpr int kK1Block = SLICER_K1_BLOCK;  // project+bin workgroup: 8 waves, two workgroups per CU at 32768 particles each
+constexpr int kK1Block = SLICER_K1_BLOCK;  // project+bin workgroup: 12 waves, two workgroups per CU at 32768 particles each
 #ifndef SLICER_K1_PER_THREAD
 #define SLICER_K1_PER_THREAD 4
 #endif
@@ -42,22 +44,6 @@ constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 
 #define SLICER_LDS_BARRIER 1
 #endif
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
-
-// Reserve one slot per lane with pred set, one LDS atomic per wave.
-__device__ __forceinline__ unsigned wave_reserve(bool pred, unsigned *counter)
-{
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0ull)
-        return 0u;
-    unsigned lane = lane_id();
-    unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned base = 0;
-    if ((int)lane == leader)
-        base = atomicAdd(counter, (unsigned)__popcll(mask));
-    base = (unsigned)__shfl((int)base, leader);
-    return base + rank;
-}
 
 template <typename T>
 __device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
