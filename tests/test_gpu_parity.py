@@ -377,20 +377,23 @@ def test_tsc_multi_type_multi_file(S, algo):
         assert np.all(d <= 3e-6 * ref_tot + atol)
 
 
+@pytest.mark.parametrize("npix", [128, 296])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_multi_plane_pass_equals_single_plane_calls(S, algo):
-    """Four planes of one box replication in one pass == four createDensityMaps-style calls (NGP: bitwise)."""
+def test_multi_plane_pass_equals_single_plane_calls(S, algo, npix):
+    """Four planes of one box replication in one pass == four createDensityMaps-style calls (NGP: bitwise).
+    npix = 296 gives an odd number of tiles per plane (19 x 19 NGP, 19 x 37 TSC): the odd planes' bins then start in
+    the middle of a packed histogram word, which the sort kernel handles on a separate path."""
     files = [one_type_file(300000)]
     lds = [3.0, 3.25, 3.5, 3.75]
     ld2s = [3.25, 3.5, 3.75, 4.0]
-    multi = run_gpu(S, files, 128, 0.25, lds, ld2s, ngp=True, algo=algo)
+    multi = run_gpu(S, files, npix, 0.25, lds, ld2s, ngp=True, algo=algo)
     for p in range(4):
-        ref_tot, _, nsel = run_oracle(files, 128, 0.25, lds[p], ld2s[p], ngp=True)
+        ref_tot, _, nsel = run_oracle(files, npix, 0.25, lds[p], ld2s[p], ngp=True)
         assert np.array_equal(multi[p][0].view(np.uint32), ref_tot.view(np.uint32))
         assert np.array_equal(multi[p][2], nsel)
-    multi_t = run_gpu(S, files, 128, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=algo)
+    multi_t = run_gpu(S, files, npix, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=algo)
     for p in range(4):
-        (single, _, _), = run_gpu(S, files, 128, 0.25, lds[p], ld2s[p], accum=slicer_amd.ACC_FIXED64, algo=algo)
+        (single, _, _), = run_gpu(S, files, npix, 0.25, lds[p], ld2s[p], accum=slicer_amd.ACC_FIXED64, algo=algo)
         assert np.array_equal(multi_t[p][0].view(np.uint32), single.view(np.uint32))
 
 
