@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--accum", default="f32", choices=["f32", "f64", "fixed64"])
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "binned"])
     ap.add_argument("--clustered", action="store_true")
+    ap.add_argument("--hydro", action="store_true",
+                    help="per-particle masses (type 0, massarr = 0: densitymaps.cpp:358-372) instead of one mass per type")
     ap.add_argument("--shard", default="snapshots", choices=["snapshots", "files"])
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
@@ -174,15 +176,23 @@ def main():
             S.synth_positions(buf.data_ptr(), ff * per_file, per_file, BOX, seed=seed0 + s, clustered=a.clustered)
             row.append(buf)
         pos.append(row)
+    masses = None
+    if a.hydro:  # one block of per-particle masses, shared by every sub-file (values in (0.5, 1.5) * MASS)
+        masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
     torch.cuda.synchronize()
 
     def step(i):
         s = i % len(my_snaps)
-        S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False)
+        S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
         for j, ff in enumerate(my_files):
-            S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                         RND["center"], RND["rcase"])
-            S.deposit_device(1, pos[s][j].data_ptr(), per_file)
+            if a.hydro:
+                S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                             RND["center"], RND["rcase"])
+                S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
+            else:
+                S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                             RND["center"], RND["rcase"])
+                S.deposit_device(1, pos[s][j].data_ptr(), per_file)
             S.file_end()
         S.plane_finalize()
         if a.shard == "files" and use_dist:
@@ -195,7 +205,7 @@ def main():
         step(s)
         d = 0
         for p in range(len(lds)):
-            d += int(_counts(S, p)[1])
+            d += int(_counts(S, p)[0 if a.hydro else 1])
         dep_per_snap.append(d)
 
     for i in range(a.warmup):
@@ -273,7 +283,7 @@ def main():
             "dtype": {"f32": "f32", "f64": "f64", "fixed64": "int64"}[a.accum] if a.mas == "tsc" else "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{a.side}^3-particle GADGET-2 boxes ({files} sub-files), {a.snapshots} snapshots/rank "
+                "workload": f"{a.side}^3-particle GADGET-2 boxes ({files} sub-files{', per-particle masses' if a.hydro else ''}), {a.snapshots} snapshots/rank "
                             f"resident in HBM, {a.npix}^2 {a.mas.upper()}, {len(lds)} lens planes per pass, "
                             f"{'clustered' if a.clustered else 'uniform'}",
                 "shard": a.shard, "algo": a.algo, "accum": a.accum,

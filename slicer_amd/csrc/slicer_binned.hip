@@ -84,10 +84,9 @@ __device__ __forceinline__ void lds_fence()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <bool VEC, bool HAS_MASS>
-__device__ __forceinline__ void load_round(const float *__restrict__ pos, const float *__restrict__ mass, uint64_t i0,
-                                           int nvalid, float (&rx)[kPerThread], float (&ry)[kPerThread],
-                                           float (&rz)[kPerThread], float (&rm)[kPerThread])
+template <bool VEC>
+__device__ __forceinline__ void load_round(const float *__restrict__ pos, uint64_t i0, int nvalid,
+                                           float (&rx)[kPerThread], float (&ry)[kPerThread], float (&rz)[kPerThread])
 {
     static_assert(kPerThread % 4 == 0, "four particles = three dwordx4 loads");
     if (VEC && nvalid == kPerThread) {
@@ -112,11 +111,6 @@ __device__ __forceinline__ void load_round(const float *__restrict__ pos, const 
             }
         }
     }
-    if (HAS_MASS) {
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++)
-            rm[k] = k < nvalid ? mass[i0 + k] : 0.f;
-    }
 }
 
 template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
@@ -133,10 +127,9 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     const int tid = threadIdx.x;
     const unsigned lane = lane_id();
     const int wave = tid >> 6;
-    // wave-private stack of float4 {x, y, z, plane bits} (+ a parallel mass array): one ds_write_b128 per push
+    // wave-private stack of float4 {x, y, z, plane | index-in-batch << 3}: one ds_write_b128 per push.  Per-particle
+    // masses are not carried along: the projection stage fetches the mass of a selected entry by that index.
     float4 *q4 = reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) + (size_t)wave * kWaveQ;
-    float *qm = reinterpret_cast<float *>(reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) +
-                                          (size_t)kWaves * kWaveQ) + (size_t)wave * kWaveQ;  // only with HAS_MASS
     __shared__ unsigned s_out[kMaxUnits], s_cnt[kMaxPlanes];
     __shared__ int s_neg;
 
@@ -157,11 +150,11 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
 
     // round r of this wave covers particles [w0 + r*kRound, +256): lane l owns 4 consecutive ones
     const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
-    float rx[kPerThread], ry[kPerThread], rz[kPerThread], rm[kPerThread];
-    float nx[kPerThread], ny[kPerThread], nz[kPerThread], nm[kPerThread];
+    float rx[kPerThread], ry[kPerThread], rz[kPerThread];
+    float nx[kPerThread], ny[kPerThread], nz[kPerThread];
     uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
     int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
-    load_round<VEC, HAS_MASS>(pos, mass, i0, nvalid, rx, ry, rz, rm);
+    load_round<VEC>(pos, i0, nvalid, rx, ry, rz);
 
     for (uint64_t r0 = w0; r0 < b1; r0 += kRound) {
         // prefetch the next round while this one is processed
@@ -169,7 +162,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
         const bool more = r0 + kRound < b1;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
         if (kPrefetch && more)
-            load_round<VEC, HAS_MASS>(pos, mass, i1, nvalid1, nx, ny, nz, nm);
+            load_round<VEC>(pos, i1, nvalid1, nx, ny, nz);
 
         // ---- transform, slab select, conservative FOV pre-test, push ----
 #pragma unroll
@@ -197,9 +190,8 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             const unsigned long long mask = __ballot(sel);
             if (sel) {
                 const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                q4[slot] = make_float4(x, y, z, __int_as_float(plane));
-                if (HAS_MASS)
-                    qm[slot] = rm[k];
+                const unsigned tag = (unsigned)plane | (HAS_MASS ? (unsigned)(i0 + k - b0) << 3 : 0u);
+                q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
             }
             top += (unsigned)__popcll(mask);
         }
@@ -215,7 +207,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             int plane = 0;
             if (lane < take) {
                 const float4 ent = q4[e];
-                plane = __float_as_int(ent.w);
+                plane = (int)(__float_as_uint(ent.w) & 7u);
                 if (project<SERIES>(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
                     valid = true;
                     int gx = grid_index<POW2>(xs, P);
@@ -238,7 +230,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                     tile_in_unit = trow * (unsigned)G.ntx + tx;
                     bin = unit * (unsigned)G.tiles_per_unit + tile_in_unit;
                     if (HAS_MASS)
-                        m = qm[e];
+                        m = mass[b0 + (__float_as_uint(ent.w) >> 3)];
                 }
             }
             top -= take;
@@ -271,11 +263,9 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 rx[k] = nx[k];
                 ry[k] = ny[k];
                 rz[k] = nz[k];
-                if (HAS_MASS)
-                    rm[k] = nm[k];
             }
         } else if (more) {
-            load_round<VEC, HAS_MASS>(pos, mass, i1, nvalid1, rx, ry, rz, rm);
+            load_round<VEC>(pos, i1, nvalid1, rx, ry, rz);
         }
         i0 = i1;
         nvalid = nvalid1;
@@ -780,7 +770,8 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 // ---------------------------------------------------------------------------------------------
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
 {
-    return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * (has_mass ? 20 : 16);
+    (void)has_mass;  // masses are fetched by index in the projection stage, not carried on the stacks
+    return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * 16;
 }
 
 template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
