@@ -397,6 +397,43 @@ def test_multi_plane_pass_equals_single_plane_calls(S, algo, npix):
         assert np.array_equal(multi_t[p][0].view(np.uint32), single.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_binned_path(S, seed):
+    """Randomised differential check of the binned pipeline: map size (power of two or not), number of planes and
+    their (contiguous or gapped) slabs, field of view, face, signs, centre, file split and particle count are drawn at
+    random; NGP maps and counters must equal the oracle's bit for bit, and the FIXED64 TSC maps those of the fused
+    direct kernel bit for bit (same contributions, order-free sums)."""
+    rng = np.random.default_rng(1000 + seed)
+    npix = int(rng.choice([64, 96, 128, 200, 256, 296, 512, 777, 1024, 2048]))
+    n_planes = int(rng.integers(1, 9))
+    edges = np.sort(rng.uniform(0.0, 1.0, 2 * n_planes))
+    if rng.random() < 0.5:  # contiguous slabs (the usual cut of a box replication)
+        edges = np.repeat(np.linspace(0.0, 1.0, n_planes + 1), 2)[1:-1]
+    rcase = float(rng.integers(0, 4))
+    lds = [rcase + float(e) for e in edges[0::2]]
+    ld2s = [rcase + float(e) for e in edges[1::2]]
+    fov = float(rng.uniform(0.05, 0.9)) / max(ld2s)          # <= the box at the far side of the last slab
+    rnd = dict(sgn=tuple(int(v) for v in rng.choice([-1, 1], 3)), face=int(rng.integers(1, 7)),
+               center=tuple(float(v) for v in rng.random(3)), rcase=rcase)
+    n = int(rng.integers(70000, 400000))
+    cut = int(rng.integers(1, n))
+    pos = synth.positions(int(rng.integers(0, 1 << 20)), n, BOX, clustered=bool(rng.random() < 0.3))
+    m = float(rng.uniform(0.001, 50.0))
+    files = [dict(npart=[0, cut, 0, 0, 0, 0], massarr=[0, m, 0, 0, 0, 0], boxsize=BOX, pos=pos[:cut]),
+             dict(npart=[0, n - cut, 0, 0, 0, 0], massarr=[0, m, 0, 0, 0, 0], boxsize=BOX, pos=pos[cut:])]
+    got = run_gpu(S, files, npix, fov, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    for p in range(n_planes):
+        ref_tot, ref_toti, nsel = run_oracle(files, npix, fov, lds[p], ld2s[p], ngp=True, rnd=rnd)
+        assert np.array_equal(got[p][2], nsel), (seed, p)
+        assert np.array_equal(got[p][0].view(np.uint32), ref_tot.view(np.uint32)), (seed, p)
+        assert np.array_equal(got[p][1].view(np.uint32), ref_toti.view(np.uint32)), (seed, p)
+    a = run_gpu(S, files, npix, fov, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    b = run_gpu(S, files, npix, fov, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_DIRECT, rnd=rnd)
+    for p in range(n_planes):
+        assert np.array_equal(a[p][2], b[p][2]), (seed, p)
+        assert np.array_equal(a[p][0].view(np.uint32), b[p][0].view(np.uint32)), (seed, p)
+
+
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
 def test_hydro_per_particle_masses_and_max_m_cap(S, algo):
     """densitymaps.cpp:358-372: per-particle masses for massarr==0 types, > MAX_M -> 0."""
