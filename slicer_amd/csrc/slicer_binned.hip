@@ -588,8 +588,7 @@ __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, 
     if (ACC == kF32 || ACC == kF64)
         atomicAdd(reinterpret_cast<double *>(cell), (double)c);  // ds_add_f64
     else if (ACC == kFixed64)
-        atomicAdd(reinterpret_cast<unsigned long long *>(cell),
-                  (unsigned long long)__double2ll_rn((double)c * P.fixed_scale));  // ds_add_u64
+        atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, P.fixed_scale));  // ds_add_u64
 }
 
 // Work items of the tile kernel: a (plane, tile) bin with many records (a halo core can put 10^5..10^7

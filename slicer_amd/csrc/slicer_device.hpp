@@ -381,6 +381,14 @@ __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, fl
     }
 }
 
+// rint(w * scale) for 0 <= w * scale < 2^51 (scale a power of two) as an integer, with one fp64 FMA: the low 52 bits
+// of w * scale + 2^52 (the product is exact, so the FMA rounds exactly once, to nearest even -- what __double2ll_rn
+// of the product returns, without its 64-bit conversion sequence)
+__device__ __forceinline__ unsigned long long rn_scaled_u64(float w, double scale)
+{
+    return (unsigned long long)__double_as_longlong(fma((double)w, scale, 0x1p52)) & 0xFFFFFFFFFFFFFull;
+}
+
 // densitymaps.cpp:367-369: masses above MAX_M (1e3) are zeroed
 __device__ __forceinline__ float cap_mass(float m) { return m > 1000.0f ? 0.0f : m; }
 
