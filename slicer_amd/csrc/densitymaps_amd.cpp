@@ -72,10 +72,14 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
                       std::valarray<float> (&mapxytoti)[6], int (&ntotxyi)[6], int myid)
 {
     const size_t np2 = (size_t)p.npix * (size_t)p.npix;
-    mapxytot.resize(np2);  // densitymaps.cpp:426-431 (valarray::resize zero-fills)
+    // densitymaps.cpp:426-431 resizes (= zero-fills) all seven maps.  Every map is either overwritten from the device
+    // or zero-filled below, so arrays that already have the right size are not touched twice (7 x 64 MiB at 4096^2).
+    if (mapxytot.size() != np2)
+        mapxytot.resize(np2);
     for (int i = 0; i < 6; i++) {
         ntotxyi[i] = 0;
-        mapxytoti[i].resize(np2);
+        if (mapxytoti[i].size() != np2)
+            mapxytoti[i].resize(np2);
     }
     if (!ensure_handle(myid))
         return 1;
@@ -179,17 +183,30 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
             std::cout << " done map*tot " << std::endl;
     }
 
-    std::vector<float> toti(6 * np2);
+    // all-types map and counters, then every per-type map straight from the device into the caller's array (types
+    // that never appeared have no device map: zeros)
     int64_t nsel[6] = {0, 0, 0, 0, 0, 0};
-    int rc = slicer_plane_read(h, 0, &mapxytot[0], toti.data(), nsel);
+    int rc = slicer_plane_read(h, 0, &mapxytot[0], nullptr, nsel);
     if (rc != SLICER_OK) {
         std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
         if (rc == SLICER_ERR_NEGATIVE_COORD)
             std::cerr << "Aborting from Rank " << myid << std::endl;  // densitymaps.cpp:343
         return 1;
     }
+    float *d_toti[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (slicer_plane_device_maps(h, 0, nullptr, d_toti) != SLICER_OK) {
+        std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+        return 1;
+    }
     for (int i = 0; i < 6; i++) {
-        std::copy(toti.begin() + i * np2, toti.begin() + (i + 1) * np2, &mapxytoti[i][0]);
+        if (d_toti[i]) {
+            if (slicer_copy_to_host(h, &mapxytoti[i][0], d_toti[i], np2 * sizeof(float)) != SLICER_OK) {
+                std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+                return 1;
+            }
+        } else {
+            mapxytoti[i] = 0.0f;
+        }
         ntotxyi[i] = g.true_counts ? (int)nsel[i] : 0;
     }
     if (myid == 0)

@@ -1,5 +1,13 @@
 #include "gadget2_reader.hpp"
 
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
 #include <cstring>
 
 namespace slicer_amd {
@@ -58,11 +66,53 @@ bool SnapshotFile::read_block(const char *name4, std::vector<float> &out)
     return out.empty() || fread(out.data(), sizeof(float), out.size(), f_) == out.size();
 }
 
+// Large reads are split over a few threads (pread on the same descriptor): one thread copies from the page cache at
+// 3-4 GB/s, which is an order of magnitude below what the pinned staging buffer -> GPU path behind it takes.
+// SLICER_AMD_READ_THREADS overrides the thread count (default: min(8, hardware threads)).
 bool SnapshotFile::read_at(long offset, void *dst, size_t bytes)
 {
-    if (!f_ || fseek(f_, offset, SEEK_SET) != 0)
+    if (!f_)
         return false;
-    return bytes == 0 || fread(dst, 1, bytes, f_) == bytes;
+    if (bytes == 0)
+        return true;
+    static const unsigned nthreads = [] {
+        const char *e = getenv("SLICER_AMD_READ_THREADS");
+        unsigned n = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1u, std::min(n, 64u));
+    }();
+    constexpr size_t kMinPerThread = 4u << 20;
+    const unsigned nt = (unsigned)std::min<size_t>(nthreads, bytes / kMinPerThread);
+    if (nt <= 1) {
+        if (fseek(f_, offset, SEEK_SET) != 0)
+            return false;
+        return fread(dst, 1, bytes, f_) == bytes;
+    }
+    const int fd = fileno(f_);
+    std::atomic<bool> ok{true};
+    auto work = [&](unsigned k) {
+        const size_t per = (bytes / nt + 4095) & ~(size_t)4095;
+        size_t lo = std::min(bytes, (size_t)k * per), hi = std::min(bytes, lo + per);
+        if (k == nt - 1)
+            hi = bytes;
+        char *p = static_cast<char *>(dst) + lo;
+        while (lo < hi) {
+            const ssize_t r = pread(fd, p, hi - lo, (off_t)offset + (off_t)lo);
+            if (r <= 0) {
+                ok = false;
+                return;
+            }
+            lo += (size_t)r;
+            p += r;
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (unsigned k = 1; k < nt; k++)
+        th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th)
+        t.join();
+    return ok;
 }
 
 bool SnapshotFile::read_masses(std::vector<float> (&mass)[6])

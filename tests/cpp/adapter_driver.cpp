@@ -1,6 +1,8 @@
 // adapter_driver.cpp -- calls createDensityMaps the way slicer-v2.cpp:138-229 does (one plane), on snapshot
 // files prepared by the pytest that launches it, and dumps the maps for comparison with the oracle.
 // usage: adapter_driver <File base> <ffmin> <ffmax> <npix> <fov_rad> <ld> <ld2> <rcase> <ngp> <hydro> <out.bin>
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -37,9 +39,18 @@ int main(int argc, char **argv)
     slicer_amd_adapter_config(atoi(argv[9]) ? 1 : 0, 0, 0, 0, 0);
     std::valarray<float> mapxytot, mapxytoti[6];
     int ntotxyi[6];
-    int rc = createDensityMaps(p, lens, random, 0, (unsigned)atoi(argv[2]), (unsigned)atoi(argv[3]), argv[1],
+    // ADAPTER_REPEAT=N: call N times and print every call's wall time (the first includes the device context)
+    const int repeat = getenv("ADAPTER_REPEAT") ? std::max(1, atoi(getenv("ADAPTER_REPEAT"))) : 1;
+    int rc = 0;
+    for (int r = 0; r < repeat && rc == 0; r++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = createDensityMaps(p, lens, random, 0, (unsigned)atoi(argv[2]), (unsigned)atoi(argv[3]), argv[1],
                                atof(argv[5]), atof(argv[8]), nullptr, nullptr, nullptr, nullptr, mapxytot, mapxytoti,
                                ntotxyi, 1);
+        if (repeat > 1)
+            fprintf(stderr, "createDensityMaps call %d: %.1f ms\n", r,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     slicer_amd_adapter_shutdown();
     if (rc)
         return 1;

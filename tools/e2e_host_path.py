@@ -19,12 +19,14 @@ base = os.path.join(d, "snap_000")
 pos = synth.positions(0, n, 1000.0)
 gadget.write_snapshot(base + ".0", pos, [0, n, 0, 0, 0, 0], [0, 0.0123, 0, 0, 0, 0], 1000.0)
 drv = os.path.join(ROOT, "tests", "cpp", "adapter_driver")
-for rep in range(3):
-    out = os.path.join(d, f"m{rep}.bin")
-    t0 = time.perf_counter()
-    r = subprocess.run([drv, base, "0", "1", str(npix), "0.25", "3.0", "3.25", "3.0", "0", "0", out], capture_output=True)
-    dt = time.perf_counter() - t0
-    print(f"C++ adapter process (incl. context creation, file read, H2D, kernels, D2H of 7 maps, dump): {dt:.3f} s rc={r.returncode}")
+for threads in ("1", "8"):
+    out = os.path.join(d, "m.bin")
+    env = dict(os.environ, ADAPTER_REPEAT="5", SLICER_AMD_READ_THREADS=threads)
+    r = subprocess.run([drv, base, "0", "1", str(npix), "0.25", "3.0", "3.25", "3.0", "0", "0", out], capture_output=True,
+                       env=env, text=True)
+    print(f"C++ createDensityMaps (file read -> pinned staging -> H2D -> kernels -> D2H of 7 maps), "
+          f"{threads} read thread(s), rc={r.returncode}:")
+    print("   " + " | ".join(l.split(": ")[1] for l in r.stderr.splitlines() if l.startswith("createDensityMaps call")))
 import slicer_amd  # noqa: E402
 S = slicer_amd.Slicer(0, max_chunk=1 << 22)
 p = slicer_amd.InputParams(npix=npix)
