@@ -299,23 +299,35 @@ int main(int argc, char **argv)
             break;
         const size_t np2 = (size_t)p.npix * (size_t)p.npix;
         std::valarray<float> tot(np2), toti[6];
-        vector<float> toti_flat(p.partinplanes ? 6 * np2 : 0);
         for (size_t k = 0; k < todo.size() && rc_all == 0; k++) {
             const int i = todo[k];
             int64_t nsel[6];
-            if (slicer_plane_read(h, (int)k, &tot[0], p.partinplanes ? toti_flat.data() : nullptr, nsel) != SLICER_OK) {
+            float *d_toti[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            if (slicer_plane_read(h, (int)k, &tot[0], nullptr, nsel) != SLICER_OK ||
+                (p.partinplanes && slicer_plane_device_maps(h, (int)k, nullptr, d_toti) != SLICER_OK)) {
                 cerr << "slicer_amd: " << slicer_last_error(h) << endl;
                 rc_all = 1;
                 break;
             }
             int ntotxyi[6];
-            for (int t = 0; t < 6; t++) {
+            for (int t = 0; t < 6 && rc_all == 0; t++) {
                 ntotxyi[t] = reference_counts ? 0 : (int)nsel[t];
-                if (p.partinplanes) {
+                if (!p.partinplanes)
+                    continue;
+                // per-type maps straight from the device into the array writeMaps gets; types without particles: zeros
+                if (toti[t].size() != np2)
                     toti[t].resize(np2);
-                    std::copy(toti_flat.begin() + t * np2, toti_flat.begin() + (t + 1) * np2, &toti[t][0]);
+                if (d_toti[t]) {
+                    if (slicer_copy_to_host(h, &toti[t][0], d_toti[t], np2 * sizeof(float)) != SLICER_OK) {
+                        cerr << "slicer_amd: " << slicer_last_error(h) << endl;
+                        rc_all = 1;
+                    }
+                } else {
+                    toti[t] = 0.0f;
                 }
             }
+            if (rc_all)
+                break;
             const double zsim = getZl.eval((lens.ld2[i] + lens.ld[i]) / 2.0);  // slicer-v2.cpp:219
             Header hd = simhdr;
             try {
