@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the mass-assignment hot path on MI355X.
 
-Metric (BASELINE.json): particles/s deposited (TSC, 4096^2 map).
-Workload at N=1 (BASELINE config[2], the configuration the metric is quoted on; it fits one GPU):
+Metric (BASELINE.json): particles/s deposited (TSC, 4096^2 map); max |dpixel| vs ref.
+Workload (BASELINE config[2], the configuration the metric is quoted on; it fits one GPU):
   4 synthetic GADGET-2 snapshots of 512^3 particles (8 sub-files of 2^24 each, raw POS blocks resident
   in HBM before the timed region), 4096^2 TSC maps, the 4 lens planes of one box replication built in
   one pass (S8d geometry: rcase=3, ld=3+{0,.25,.5,.75}, fov=0.25 rad, face 3, signs (-,+,-),
   centre (.3,.6,.1)).  One step = one snapshot -> its 4 plane maps: plane_begin (zero) + 8 sub-file
   deposits + finalize.  Steps cycle through the resident snapshots.
-N>1: one process per GPU (torchrun), each rank owns its own snapshots (planes / snapshots shard with no
-  data-path exchange: SURVEY S8e level 2) => "scaling": "weak"; value = all ranks' deposits / max time.
-  --shard files switches to the reference's own partition (slicer-v2.cpp:162-175: sub-files of every
-  snapshot split over ranks) followed by the per-plane sum to rank 0 (slicer-v2.cpp:214-217) over RCCL.
-
-Prints ONE JSON line on rank 0.
+N > 1 (one process per GPU; `python bench.py --gpus N` starts the N ranks itself when no launcher did):
+  --shard files (default, "scaling": "strong"): the SAME job, split the way the reference splits it -- every
+      snapshot's sub-files in contiguous ranges over the ranks (slicer-v2.cpp:162-175) -- followed by the per-plane
+      sum to rank 0 (slicer-v2.cpp:214-217) over RCCL/xGMI, in the accumulator's own type; the sum of step i
+      overlaps the deposits of step i+1 (two handles, RCCL on its own stream).
+  --shard snapshots ("weak"): every rank owns its own boxes, no data-path collective (SURVEY S8e level 2).
+value = deposits of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,7 +34,9 @@ LDS = [3.0, 3.25, 3.5, 3.75]
 LD2S = [3.25, 3.5, 3.75, 4.0]
 FOV = 0.25
 MASS = 0.0123
-HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6.29e12 measured-achievable
+SEED = 0x51CE2
+HBM_PEAK = 8.0e12    # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6.29e12 measured-achievable
+PCIE_PEAK = 63.0e9   # B/s, PCIe Gen5 x16
 
 
 def parse():
@@ -49,10 +55,16 @@ def parse():
     ap.add_argument("--clustered", action="store_true")
     ap.add_argument("--hydro", action="store_true",
                     help="per-particle masses (type 0, massarr = 0: densitymaps.cpp:358-372) instead of one mass per type")
-    ap.add_argument("--shard", default="snapshots", choices=["snapshots", "files"])
+    ap.add_argument("--shard", default="auto", choices=["auto", "snapshots", "files"],
+                    help="auto: files (strong scaling + per-plane RCCL reduce) when N > 1")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
     ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--parity", default="auto", choices=["auto", "on", "off"],
+                    help="max |dpixel| vs the oracle on one sub-file of the workload (outside the timed region)")
+    ap.add_argument("--e2e", default="auto", choices=["auto", "on", "off"],
+                    help="file -> C++ createDensityMaps -> host maps timing (outside the timed region)")
     ap.add_argument("--profile-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -60,57 +72,141 @@ def parse():
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a scalar port of the reference path) on the host cores, parallelised the
 # way the reference is (one process per contiguous sub-file range, slicer-v2.cpp:162-175).  Each
-# worker builds the 4 planes of its own sub-file with 4 createDensityMaps-equivalent calls, exactly
-# what slicer-v2.cpp's plane loop does (the reference re-reads the snapshot for every plane).
+# worker builds the planes of its own sub-file with one createDensityMaps-equivalent call per plane,
+# exactly what slicer-v2.cpp's plane loop does (the reference re-reads the snapshot for every plane).
+#   compute-only:        positions already in RAM when the clock starts (the oracle still zeroes six per-type
+#                        maps per file and runs the map-wide sums of densitymaps.cpp:496-513, as the reference does)
+#   reference-faithful:  + the reference's read pattern: three 4-byte stream reads per particle from the
+#                        (page-cached) POS block, once per plane (gadget2io.cpp:200-202)
+# Worker 0 owns sub-file 0 of snapshot 0 of the GPU workload and hands its maps back: they are the
+# oracle side of "max |dpixel| vs ref".
 # ------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    first, n, npix, ngp, planes, clustered = args
-    import numpy as np  # noqa: F401
-
+    first, n, npix, ngp, planes, clustered, faithful, want_maps = args
     import oracle
     from slicer_amd import synth
-    pos = synth.positions(first, n, BOX, clustered=clustered)
+    pos = synth.positions(first, n, BOX, seed=SEED, clustered=clustered)
     f = dict(npart=[0, n, 0, 0, 0, 0], massarr=[0, MASS, 0, 0, 0, 0], boxsize=BOX, pos=pos)
     oracle.lib()
+    path = None
+    if faithful:
+        fd, path = tempfile.mkstemp(prefix="slicer_cpu_", suffix=".pos", dir="/tmp")
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(pos.tobytes())
     t0 = time.perf_counter()
-    dep = 0
+    dep, maps = 0, []
     for p in range(planes):
+        if faithful:
+            _faithful_read(path, n)  # buffered stream, 3 reads of 4 bytes per particle
         rc, tot, toti, nsel = oracle.create_density_maps([f], 0, 1, npix, False, ngp, LDS[p], LD2S[p], 0, FOV,
                                                          RND["sgn"], RND["face"], RND["center"], RND["rcase"])
         dep += int(nsel[1])
-    return time.perf_counter() - t0, dep
+        if want_maps:
+            maps.append(tot.copy())
+    dt = time.perf_counter() - t0
+    if path:
+        os.unlink(path)
+    return dt, dep, maps
 
 
-def cpu_baseline(a):
+def _faithful_read(path, n):
+    """3 x fin.read(4 bytes) per particle (gadget2io.cpp:200-202) through a buffered stream; the loop is native
+    (oracle/slicer_oracle.c: orc_stream_read_pos)."""
+    import ctypes
+
+    import oracle
+    L = oracle.lib()
+    L.orc_stream_read_pos.restype = ctypes.c_long
+    L.orc_stream_read_pos.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.POINTER(ctypes.c_float)]
+    sink = ctypes.c_float()
+    got = L.orc_stream_read_pos(path.encode(), n, ctypes.byref(sink))
+    assert got == n, (got, n)
+
+
+def cpu_baseline(a, want_maps):
     import multiprocessing as mp
-    cores = a.cpu_cores or max(1, min(16, len(os.sched_getaffinity(0))))
+    avail = len(os.sched_getaffinity(0))
+    cores = a.cpu_cores or max(1, min(16, avail))
     n = a.cpu_particles
     ctx = mp.get_context("spawn")
-    jobs = [(i * n, n, a.npix, a.mas == "ngp", a.planes, a.clustered) for i in range(cores)]
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
-    wall = max(r[0] for r in res)  # compute-only: workers generate their inputs before the clock starts
-    dep = sum(r[1] for r in res)
-    return {"value": dep / wall, "unit": "particles/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} sub-files x {n} particles, {a.planes} planes each ({a.planes} createDensityMaps-"
-                      f"equivalent oracle calls per sub-file, one process per sub-file), {a.npix}^2 "
-                      f"{a.mas.upper()}; {wall:.1f} s wall, inputs in RAM",
-            "n_in_per_s": cores * n * a.planes / wall, "total_s": time.perf_counter() - t0}
+    out = {"unit": "particles/s", "kind": "port"}
+    ref_maps = None
+
+    def run(ncores, faithful, maps):
+        jobs = [(i * n, n, a.npix, a.mas == "ngp", a.planes, a.clustered, faithful, maps and i == 0)
+                for i in range(ncores)]
+        with ctx.Pool(ncores) as pool:
+            res = pool.map(_cpu_worker, jobs)
+        wall = max(r[0] for r in res)
+        return sum(r[1] for r in res) / wall, ncores * n * a.planes / wall, wall, res[0][2]
+
+    v, vin, wall, ref_maps = run(cores, False, want_maps)
+    out.update(value=v, cores=cores, n_in_per_s=vin,
+               sample=f"compute-only: {cores} sub-files x {n} particles, {a.planes} planes each ({a.planes} "
+                      f"createDensityMaps-equivalent oracle calls per sub-file, one process per sub-file), {a.npix}^2 "
+                      f"{a.mas.upper()}; {wall:.1f} s wall, inputs in RAM")
+    if a.cpu != "off":
+        v1, vin1, w1, _ = run(1, False, False)
+        vf, vinf, wf, _ = run(cores, True, False)
+        out["variants"] = {
+            "compute_only_R1": {"value": v1, "cores": 1, "n_in_per_s": vin1, "wall_s": w1},
+            f"reference_faithful_R{cores}": {"value": vf, "cores": cores, "n_in_per_s": vinf, "wall_s": wf,
+                                             "what": "compute-only + 3 buffered stream reads of 4 B per particle from a "
+                                                     "page-cached POS file, per plane (gadget2io.cpp:200-202)"},
+        }
+    out["total_s"] = time.perf_counter() - t0
+    return out, ref_maps
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the rank processes ourselves, before anything touches a GPU
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(a):
+    import torch  # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} needs {a.gpus} devices, this node shows {have} "
+                         f"(it will not silently run on fewer)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    line = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if any(codes) or not line:
+        raise SystemExit(f"rank exit codes {codes}; no result line" if not line else f"rank exit codes {codes}")
+    print(line[-1], flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
+        if world == 1:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is 1: refusing to report a {a.gpus}-GPU number from one rank")
         a.gpus = world
+    shard = a.shard if a.shard != "auto" else ("files" if world > 1 else "snapshots")
 
-    cpu = None
+    cpu, ref_maps = None, None
+    want_parity = a.parity == "on" or (a.parity == "auto" and a.mas == "tsc" and a.side ** 3 // a.files >= a.cpu_particles
+                                       and not a.hydro)
     if rank == 0 and world == 1 and a.cpu != "off":
-        cpu = cpu_baseline(a)  # before anything touches the GPU in this process
+        cpu, ref_maps = cpu_baseline(a, want_parity)  # before anything touches the GPU in this process
+    elif rank == 0 and want_parity and a.parity == "on":
+        _, _, ref_maps = _cpu_worker((0, a.cpu_particles, a.npix, a.mas == "ngp", a.planes, a.clustered, False, True))
 
     import torch  # first, so that libslicer_amd.so binds to the HIP runtime torch already loaded
     import torch.distributed as dist
@@ -120,6 +216,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: needs device {local_rank}, node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("SLICER_BENCH_FORCE_DIST") == "1"  # the latter: rehearse on one GPU
     if use_dist:
@@ -151,65 +249,98 @@ def main():
     lds, ld2s = LDS[:a.planes], LD2S[:a.planes]
     if a.planes == 1:
         lds, ld2s = [3.0], [3.25]
+    ptype = 0 if a.hydro else 1
 
-    S = slicer_amd.Slicer(local_rank, max_chunk=per_file)
-    stream = torch.cuda.current_stream()
-    S.set_stream(stream.cuda_stream)
+    reduce_steps = shard == "files" and use_dist
+    overlap = reduce_steps and not a.no_overlap
+    # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and workspace
+    # and works on its own stream; RCCL runs on torch.distributed's communication stream.
+    n_handles = 2 if overlap else 1
+    handles = [slicer_amd.Slicer(local_rank, max_chunk=per_file) for _ in range(n_handles)]
+    streams = [torch.cuda.Stream() for _ in range(n_handles)] if overlap else [torch.cuda.current_stream()]
+    for S, st in zip(handles, streams):
+        S.set_stream(st.cuda_stream)
+    S0 = handles[0]
 
     # which sub-files of which snapshots this rank deposits
-    if a.shard == "snapshots":
-        my_snaps = list(range(a.snapshots))
-        seed0 = 0x51CE2 + 1000 * rank          # every rank owns different boxes
+    my_snaps = list(range(a.snapshots))
+    if shard == "snapshots":
+        seed0 = SEED + 1000 * rank          # every rank owns different boxes
         my_files = list(range(files))
     else:
-        my_snaps = list(range(a.snapshots))
-        seed0 = 0x51CE2                         # same boxes everywhere, sub-files split as slicer-v2.cpp:162-175
+        seed0 = SEED                        # same boxes everywhere, sub-files split as slicer-v2.cpp:162-175
         lo, hi = parallel.file_range(files, world, rank)
         my_files = list(range(lo, hi))
 
     # resident raw POS blocks: [snapshot][file] -> torch buffer (HBM)
     pos = []
-    for s in my_snaps:
-        row = []
-        for ff in my_files:
-            buf = torch.empty(per_file * 3, dtype=torch.float32, device="cuda")
-            S.synth_positions(buf.data_ptr(), ff * per_file, per_file, BOX, seed=seed0 + s, clustered=a.clustered)
-            row.append(buf)
-        pos.append(row)
-    masses = None
-    if a.hydro:  # one block of per-particle masses, shared by every sub-file (values in (0.5, 1.5) * MASS)
-        masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
+    with torch.cuda.stream(streams[0]):
+        for s in my_snaps:
+            row = []
+            for ff in my_files:
+                buf = torch.empty(per_file * 3, dtype=torch.float32, device="cuda")
+                S0.synth_positions(buf.data_ptr(), ff * per_file, per_file, BOX, seed=seed0 + s, clustered=a.clustered)
+                row.append(buf)
+            pos.append(row)
+        masses = None
+        if a.hydro:  # one block of per-particle masses, shared by every sub-file (values in (0.5, 1.5) * MASS)
+            masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
     torch.cuda.synchronize()
 
-    def step(i):
-        s = i % len(my_snaps)
-        S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
-        for j, ff in enumerate(my_files):
-            if a.hydro:
-                S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                             RND["center"], RND["rcase"])
-                S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
-            else:
-                S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                             RND["center"], RND["rcase"])
-                S.deposit_device(1, pos[s][j].data_ptr(), per_file)
-            S.file_end()
-        S.plane_finalize()
-        if a.shard == "files" and use_dist:
-            # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL reduce over xGMI
-            parallel.reduce_planes(S, dist, torch, root=0, per_type=False)
+    pending = [None] * n_handles  # async rank-sum works of the handle's previous step
 
-    # deposits per step (identical for a given snapshot every time it is processed)
+    def settle(k):
+        """Step k's rank sum has to be complete before its accumulators become f32 maps (and are reused)."""
+        if pending[k] is not None:
+            with torch.cuda.stream(streams[k]):
+                for w in pending[k]:
+                    w.wait()
+                handles[k].plane_finalize()
+            pending[k] = None
+
+    def step(i):
+        k = i % n_handles
+        S = handles[k]
+        settle(k)
+        s = i % len(my_snaps)
+        with torch.cuda.stream(streams[k]):
+            S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
+            for j, ff in enumerate(my_files):
+                if a.hydro:
+                    S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                                 RND["center"], RND["rcase"])
+                    S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
+                else:
+                    S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                                 RND["center"], RND["rcase"])
+                    S.deposit_device(1, pos[s][j].data_ptr(), per_file)
+                S.file_end()
+            if reduce_steps:
+                # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL over xGMI, on the accumulators
+                # (f32 / f64 / fixed point), converted to f32 maps once, after the sum
+                if overlap:
+                    pending[k] = parallel.reduce_planes(S, dist, torch, root=0, async_op=True)
+                else:
+                    parallel.reduce_planes(S, dist, torch, root=0)
+            else:
+                S.plane_finalize()
+
+    def drain():
+        for k in range(n_handles):
+            settle(k)
+
+    # deposits per step (identical for a given snapshot every time it is processed); with --shard files the counters
+    # on rank 0 are the rank sums (reduced with the maps)
     dep_per_snap = []
     for s in range(len(my_snaps)):
         step(s)
-        d = 0
-        for p in range(len(lds)):
-            d += int(_counts(S, p)[0 if a.hydro else 1])
-        dep_per_snap.append(d)
+        drain()
+        dep_per_snap.append(sum(int(_counts(handles[s % n_handles], p)[ptype]) for p in range(len(lds))))
+    algo_mask = S0.algo_mask()
 
     for i in range(a.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -217,6 +348,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -229,34 +361,35 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([my_dep, my_in], dtype=torch.float64, device="cuda")
+        # --shard files: rank 0's counters already hold the sums over ranks; the others' are partial -> take rank 0's
+        c = torch.tensor([my_dep if (not reduce_steps or rank == 0) else 0, my_in], dtype=torch.float64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_dep, tot_in = float(c[0].item()), float(c[1].item())
-        if a.shard == "files":
-            pass
     else:
         tot_dep, tot_in = float(my_dep), float(my_in)
 
     # per-kernel durations, live, with HIP events on the launch stream (a few extra untimed steps)
-    S.profile_reset()
-    S.profile_enable(True)
-    for i in range(max(1, a.profile_steps)):
+    S0.profile_reset()
+    S0.profile_enable(True)
+    for i in range(max(1, a.profile_steps) * n_handles):
         step(i)
+    drain()
     torch.cuda.synchronize()
-    S.profile_enable(False)
-    prof = S.profile_get()
+    S0.profile_enable(False)
+    prof = S0.profile_get()
     dom_name, (dom_n, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
     kernels = {k: {"launches": v[0], "avg_us": 1e3 * v[1] / max(v[0], 1)} for k, v in prof.items()}
     # algorithmic bytes per launch of the dominant kernel (DESIGN.md "Algorithmic bytes")
-    per_launch_particles = per_file
+    # (the profiled handle ran max(1, profile_steps) steps; every project_bin launch streams one sub-file)
+    dep_per_step_rank = (my_dep / max(a.steps, 1)) * (len(my_files) / files if reduce_steps else 1.0)
     if dom_name in ("direct_deposit", "project_bin"):
-        alg_bytes = 12.0 * per_launch_particles
-    elif dom_name in ("tile_deposit", "bin_scatter"):
-        alg_bytes = 8.0 * (my_dep / max(a.steps, 1)) / max(len(my_files), 1)
+        alg_bytes = 12.0 * per_file
+    elif dom_name in ("tile_deposit", "bin_scatter", "bin_sort"):
+        alg_bytes = 8.0 * dep_per_step_rank * max(1, a.profile_steps) / max(dom_n, 1)
     else:
         alg_bytes = 4.0 * a.npix * a.npix
     achieved = alg_bytes / (1e-3 * dom_ms / max(dom_n, 1))
-    traffic = None
+    traffic, traffic_step = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -264,8 +397,43 @@ def main():
             ent = tj.get(dom_name)
             if ent and ent.get("workload") == f"{a.side}^3/{a.npix}/{a.mas}/{a.algo}/{a.accum}":
                 traffic = ent.get("hbm_bytes_per_launch")
+            ws = tj.get("whole_step")
+            if ws and ws.get("workload") == f"{a.side}^3/{a.npix}/{a.mas}/{a.algo}/{a.accum}":
+                traffic_step = ws
         except Exception:
             traffic = None
+
+    # ---- max |dpixel| vs ref: sub-file 0 of snapshot 0 through the same configuration, against the oracle's maps
+    parity = None
+    if rank == 0 and ref_maps:
+        import numpy as np
+        n_par = a.cpu_particles
+        S0.set_stream(0)
+        S0.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False)
+        S0.file_begin([0, n_par, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        buf = torch.empty(n_par * 3, dtype=torch.float32, device="cuda")
+        S0.synth_positions(buf.data_ptr(), 0, n_par, BOX, seed=SEED, clustered=a.clustered)
+        S0.deposit_device(1, buf.data_ptr(), n_par)
+        S0.file_end()
+        max_abs, max_rel, max_ref = 0.0, 0.0, 0.0
+        for p in range(len(lds)):
+            got, _, _ = S0.plane_read(p, want_types=False)
+            ref = ref_maps[p].reshape(got.shape)
+            d = np.abs(got.astype(np.float64) - ref)
+            nz = ref > 0
+            max_abs = max(max_abs, float(d.max()))
+            max_rel = max(max_rel, float((d[nz] / ref[nz]).max()))
+            max_ref = max(max_ref, float(ref.max()))
+        parity = {"max_abs_dpixel": max_abs, "max_rel_dpixel": max_rel, "max_pixel": max_ref,
+                  "sample": f"sub-file 0 of snapshot 0 ({n_par} particles), {len(lds)} planes, {a.npix}^2 "
+                            f"{a.mas.upper()}, accum {a.accum}, vs oracle (parity unpinned by a reference build: DESIGN.md S2)",
+                  "algo_mask": S0.algo_mask()}
+        del buf
+
+    # ---- end to end: page-cached format-2 file -> C++ createDensityMaps adapter -> maps in host memory
+    e2e = None
+    if rank == 0 and world == 1 and (a.e2e == "on" or (a.e2e == "auto" and a.cpu != "off")):
+        e2e = end_to_end(a)
 
     if rank == 0:
         out = {
@@ -278,30 +446,67 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True,
-            "scaling": "weak" if a.shard == "snapshots" else "strong",
+            "scaling": "weak" if shard == "snapshots" else "strong",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f64": "f64", "fixed64": "int64"}[a.accum] if a.mas == "tsc" else "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{a.side}^3-particle GADGET-2 boxes ({files} sub-files{', per-particle masses' if a.hydro else ''}), {a.snapshots} snapshots/rank "
+                "workload": f"{a.side}^3-particle GADGET-2 boxes ({files} sub-files{', per-particle masses' if a.hydro else ''}), {a.snapshots} snapshots "
                             f"resident in HBM, {a.npix}^2 {a.mas.upper()}, {len(lds)} lens planes per pass, "
                             f"{'clustered' if a.clustered else 'uniform'}",
-                "shard": a.shard, "algo": a.algo, "accum": a.accum,
-                "particles_in_per_step": per_file * len(my_files),
-                "particles_deposited_per_step": my_dep / max(a.steps, 1),
+                "shard": shard, "algo": a.algo, "accum": a.accum, "algo_mask": algo_mask,
+                "collective": ("per-plane sum to rank 0 in the accumulator type over RCCL, "
+                               + ("overlapped with the next step" if overlap else "not overlapped")) if reduce_steps else None,
+                "particles_in_per_step": per_file * (files if shard == "files" else len(my_files)),
+                "particles_deposited_per_step": tot_dep / max(a.steps, 1) / (1 if shard == "files" else world),
             },
             "n_in_per_s": tot_in / dt,
             "hbm_read_roofline_frac_whole_step": 12.0 * tot_in / dt / HBM_PEAK / world,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": 1e3 * dom_ms / max(dom_n, 1)},
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": 1e3 * dom_ms / max(dom_n, 1),
+                         "whole_step_traffic": traffic_step},
             "kernels": kernels,
+            "max_rel_dpixel": parity["max_rel_dpixel"] if parity else None,
+            "parity": parity,
+            "e2e": e2e,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    S.close()
+    for S in handles:
+        S.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def end_to_end(a):
+    """One sub-file (2^24 particles) written as a format-2 file, page cached; tests/cpp/adapter_driver calls the C++
+    createDensityMaps adapter on it five times (file read -> pinned staging -> H2D -> kernels -> D2H of the maps)."""
+    import numpy as np  # noqa: F401
+
+    from slicer_amd import gadget, synth
+    drv = os.path.join(ROOT, "tests", "cpp", "adapter_driver")
+    if not os.path.exists(drv):
+        return {"error": "tests/cpp/adapter_driver not built"}
+    n = 1 << 24
+    d = tempfile.mkdtemp(prefix="slicer_e2e_", dir="/tmp")
+    base = os.path.join(d, "snap_000")
+    try:
+        gadget.write_snapshot(base + ".0", synth.positions(0, n, BOX, seed=SEED), [0, n, 0, 0, 0, 0],
+                              [0, MASS, 0, 0, 0, 0], BOX)
+        env = dict(os.environ, ADAPTER_REPEAT="5", SLICER_AMD_READ_THREADS="8")
+        r = subprocess.run([drv, base, "0", "1", str(a.npix), str(FOV), "3.0", "3.25", "3.0", "0", "0",
+                            os.path.join(d, "m.bin")], capture_output=True, env=env, text=True, timeout=300)
+        ms = [float(ln.split(": ")[1].split()[0]) for ln in r.stderr.splitlines() if ln.startswith("createDensityMaps call")]
+        if r.returncode or len(ms) < 2:
+            return {"error": f"adapter_driver rc={r.returncode}"}
+        best = min(ms[1:])
+        return {"value": n / (best * 1e-3), "unit": "input particles/s", "ms_per_call": best, "calls_ms": ms,
+                "pcie_frac": 12.0 * n / (best * 1e-3) / PCIE_PEAK,
+                "what": f"page-cached format-2 file ({n} particles) -> C++ createDensityMaps (one plane, {a.npix}^2 TSC) -> "
+                        "all-types map + populated per-type map in host memory; 8 read threads; best of 4 warm calls"}
+    finally:
+        subprocess.call(["rm", "-rf", d])
 
 
 def _counts(S, plane):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SLICER_AMD_VERSION 100 /* 0.1.0 */
+#define SLICER_AMD_VERSION 200 /* 0.2.0 */
 #define SLICER_MAX_PLANES 8
 
 /* status codes */
@@ -64,7 +64,14 @@ extern "C" {
 /* deposit algorithm */
 #define SLICER_ALGO_AUTO 0
 #define SLICER_ALGO_DIRECT 1 /* fused project + global atomics                                   */
-#define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush */
+#define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush.  An explicit
+                             * BINNED request that the geometry cannot honour returns SLICER_ERR_UNSUPPORTED;
+                             * only SLICER_ALGO_AUTO falls back to DIRECT (slicer_plane_algo_mask tells which ran). */
+
+/* element kind of an accumulator map (slicer_plane_accumulators) */
+#define SLICER_ELEM_F32 0
+#define SLICER_ELEM_F64 1
+#define SLICER_ELEM_FIXED64 2 /* u64, value = integer * 2^-fixed_exp */
 
 typedef struct slicer_handle_s *slicer_handle;
 
@@ -147,6 +154,40 @@ int slicer_synchronize(slicer_handle h);
 int slicer_get_stream(slicer_handle h, void **hip_stream);
 int slicer_plane_info(slicer_handle h, int32_t *npix, int32_t *n_planes); /* of the current plane pass */
 int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
+
+/* Which deposit algorithms ran since slicer_plane_begin: bit SLICER_ALGO_DIRECT, bit SLICER_ALGO_BINNED
+ * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0). */
+int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
+/* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
+ * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */
+int slicer_plane_status(slicer_handle h);
+
+/* ---- cross-rank sum in the accumulator type ("reduce in the accumulator type, convert after") ----
+ * Sequence per plane pass, on every rank, after the last slicer_file_end():
+ *   slicer_plane_flush()              all deposits issued into the accumulators (no conversion yet)
+ *   slicer_reduce_meta_get(&m)        which accumulators this rank holds + FIXED64 scales
+ *   <combine m across ranks: element-wise MAX of m.v[], e.g. one small all-reduce>
+ *   slicer_reduce_meta_set(&m)        allocates and zero-fills the accumulators this rank lacks, so that the SET OF
+ *                                     COLLECTIVES IS THE SAME ON EVERY RANK (the reference reduces all 7 maps
+ *                                     unconditionally, slicer-v2.cpp:214-217); fails if two ranks scaled the same
+ *                                     FIXED64 accumulator differently
+ *   slicer_plane_accumulators(p,...)  device pointers + element kind; sum them over ranks (ncclFloat / ncclDouble /
+ *                                     ncclUint64: a FIXED64 N-rank sum is bitwise the 1-rank sum)
+ *   slicer_plane_finalize()           on the root: accumulators -> f32 maps (once, after the sum)
+ * slicer_amd_rccl.h wraps this sequence for RCCL; slicer_amd/parallel.py for torch.distributed. */
+#define SLICER_REDUCE_META_INTS 24
+typedef struct {
+    /* v[0..6]   1 if accumulator slot s is live (s = type 0..5; s = 6: the shared all-types accumulator), else 0
+     * v[7..13]  FIXED64 exponent of slot s, or INT32_MIN when not live / not FIXED64
+     * v[14..20] minus that exponent, or INT32_MIN (so that an element-wise MAX exposes disagreeing ranks)
+     * v[21]     negativity-guard flag of this rank (0/1)    v[22..23] reserved (0) */
+    int32_t v[SLICER_REDUCE_META_INTS];
+} slicer_reduce_meta;
+int slicer_plane_flush(slicer_handle h);
+int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m);
+int slicer_reduce_meta_set(slicer_handle h, const slicer_reduce_meta *m);
+/* acc[s] (s as above; NULL when not live), element kind SLICER_ELEM_* (one kind per pass), npix^2 elements each. */
+int slicer_plane_accumulators(slicer_handle h, int plane, void **acc /* [7] */, int32_t *elem_kind);
 
 /* --- utilities for benches and tests (device-side synthetic boxes) --- */
 int slicer_device_malloc(slicer_handle h, size_t bytes, void **d_ptr);

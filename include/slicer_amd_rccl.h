@@ -28,9 +28,15 @@ int slicer_rccl_comm_init_all(slicer_rccl_comm *out /* [ndev] */, int ndev, cons
 int slicer_rccl_comm_destroy(slicer_rccl_comm c);
 const char *slicer_rccl_last_error(void);
 
-/* Sum every finalized map of the current plane pass of `h` onto `root`: the all-types map of each
- * plane, the six per-type maps when per_type != 0 (the reference always sends them, even when
- * partinplanes == false and nothing reads them), and the selected-particle counters. */
+/* Sum the current plane pass of `h` over the ranks onto `root`.  Call after the last slicer_file_end() and
+ * INSTEAD of slicer_plane_finalize(): the sum runs on the accumulators, in their own type (f32 / f64 / 64-bit
+ * fixed point: SURVEY S8e "reduce in the accumulator type, convert after"), and the conversion to f32 maps
+ * happens once, afterwards.  A FIXED64 N-rank result is therefore bitwise the 1-rank result.  The set of
+ * collectives is the same on every rank even when a rank's sub-files hold no particle of some type (it
+ * contributes a zero map, like the reference, which reduces all 7 maps unconditionally); the negativity guard
+ * of any rank reaches every rank (slicer_plane_read / slicer_plane_status then return SLICER_ERR_NEGATIVE_COORD).
+ * per_type is ignored (kept for source compatibility): the per-type maps are summed iff the pass keeps them
+ * (want_type_maps).  Counters of selected particles are summed too (the reference forgets to). */
 int slicer_rccl_plane_reduce(slicer_handle h, slicer_rccl_comm c, int root, int per_type);
 
 #ifdef __cplusplus

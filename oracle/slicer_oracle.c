@@ -336,3 +336,26 @@ void orc_reduce_sum(float *dst, const float *src, size_t n)
     for (size_t i = 0; i < n; i++)
         dst[i] = dst[i] + src[i];
 }
+
+/* The reference's read pattern for the POS block: three 4-byte stream reads per particle
+ * (gadget2io.cpp:200-202, fin.read((char*)&num_float1, sizeof(num_float1)) x 3) through a buffered
+ * stream.  Used by bench.py's "reference-faithful" CPU baseline variant only: it returns the number of
+ * particles read and folds the values into *sink so that the reads cannot be optimised away. */
+#include <stdio.h>
+long orc_stream_read_pos(const char *path, long n, float *sink)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return -1;
+    float a = 0.f, b = 0.f, c = 0.f, s = 0.f;
+    long i;
+    for (i = 0; i < n; i++) {
+        if (fread(&a, sizeof a, 1, f) != 1 || fread(&b, sizeof b, 1, f) != 1 || fread(&c, sizeof c, 1, f) != 1)
+            break;
+        s += a + b + c;
+    }
+    fclose(f);
+    if (sink)
+        *sink = s;
+    return i;
+}

@@ -22,6 +22,13 @@ class FileDesc(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+REDUCE_META_INTS = 24
+
+
+class ReduceMeta(C.Structure):
+    _fields_ = [("v", C.c_int32 * REDUCE_META_INTS)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -47,6 +54,12 @@ SYMBOLS = {
     "slicer_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "slicer_plane_info": (C.c_int, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "slicer_plane_device_counts": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
+    "slicer_plane_algo_mask": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "slicer_plane_status": (C.c_int, [_H]),
+    "slicer_plane_flush": (C.c_int, [_H]),
+    "slicer_reduce_meta_get": (C.c_int, [_H, C.POINTER(ReduceMeta)]),
+    "slicer_reduce_meta_set": (C.c_int, [_H, C.POINTER(ReduceMeta)]),
+    "slicer_plane_accumulators": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "slicer_device_malloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "slicer_device_free": (C.c_int, [_H, C.c_void_p]),
     "slicer_copy_to_device": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t]),

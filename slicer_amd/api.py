@@ -18,7 +18,9 @@ _L = _lib.load()
 MAS_TSC, MAS_NGP = 0, 1
 ACC_F32, ACC_F64, ACC_FIXED64 = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_BINNED = 0, 1, 2
+ELEM_F32, ELEM_F64, ELEM_FIXED64 = 0, 1, 2
 ERR_NEGATIVE_COORD = 1
+ERR_UNSUPPORTED = 6
 
 
 class SlicerError(RuntimeError):
@@ -171,6 +173,42 @@ class Slicer:
 
     def synchronize(self):
         self._chk(_L.slicer_synchronize(self._h))
+
+    def algo_mask(self):
+        """Bit (1 << ALGO_*) of every deposit algorithm that ran since plane_begin (bit 3: shot-noise thinning)."""
+        m = C.c_int32()
+        self._chk(_L.slicer_plane_algo_mask(self._h, C.byref(m)))
+        return m.value
+
+    def plane_status(self):
+        self._chk(_L.slicer_plane_status(self._h))
+
+    def plane_flush(self):
+        self._chk(_L.slicer_plane_flush(self._h))
+
+    # --- cross-rank sum in the accumulator type (include/slicer_amd.h "cross-rank sum") ---
+    def reduce_meta_get(self):
+        m = _lib.ReduceMeta()
+        self._chk(_L.slicer_reduce_meta_get(self._h, C.byref(m)))
+        return [int(x) for x in m.v]
+
+    def reduce_meta_set(self, ints):
+        m = _lib.ReduceMeta()
+        for i, x in enumerate(ints):
+            m.v[i] = int(x)
+        self._chk(_L.slicer_reduce_meta_set(self._h, C.byref(m)))
+
+    def plane_accumulators(self, plane=0):
+        """(device pointers of the 7 accumulator slots or None, ELEM_* kind); slot 6 = shared / all-types."""
+        acc = (C.c_void_p * 7)()
+        elem = C.c_int32()
+        self._chk(_L.slicer_plane_accumulators(self._h, int(plane), acc, C.byref(elem)))
+        return [acc[s] for s in range(7)], elem.value
+
+    def plane_device_counts(self, plane=0):
+        p = C.c_void_p()
+        self._chk(_L.slicer_plane_device_counts(self._h, int(plane), C.byref(p)))
+        return p.value
 
     def plane_device_maps(self, plane=0):
         tot = C.c_void_p()

@@ -61,6 +61,8 @@ struct slicer_handle_s {
     int *d_neg = nullptr;
     bool type_seen[6] = {};       // in this plane pass
     bool shared_seen = false;
+    int algo_mask = 0;            // bit (1 << SLICER_ALGO_*) of every algorithm that ran in this pass; bit 3 = thinning
+    bool neg_remote = false;      // another rank reported the negativity guard (slicer_reduce_meta_set)
     int file_mode[6] = {};        // NGP fold mode of the current file
     float file_mconst[6] = {};
     int fixed_exp[6] = {};
@@ -93,6 +95,7 @@ struct slicer_handle_s {
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> ev_pool;
+    uint64_t prof_event_failures = 0;
     double prof_ms[KN_COUNT] = {};
     uint64_t prof_n[KN_COUNT] = {};
 };
@@ -123,16 +126,22 @@ int fail(slicer_handle h, int code, const char *fmt, ...)
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-int ensure(slicer_handle h, DevBuf &b, size_t bytes)
+// Grow-only device buffer.  *fresh (optional) is set when the buffer was (re)allocated: its contents are undefined
+// (the new allocation may even reuse the old address, so callers must not compare pointers).
+int ensure(slicer_handle h, DevBuf &b, size_t bytes, bool *fresh = nullptr)
 {
+    if (fresh)
+        *fresh = false;
     if (b.cap >= bytes)
         return SLICER_OK;
     if (b.p)
-        HIPCHK(h, hipFree(b.p));
+        HIPCHK(h, hipFree(b.p));  // implicit device synchronisation: happens only while a workspace still grows
     b.p = nullptr;
     b.cap = 0;
     HIPCHK(h, hipMalloc(&b.p, bytes));
     b.cap = bytes;
+    if (fresh)
+        *fresh = true;
     return SLICER_OK;
 }
 
@@ -152,7 +161,8 @@ hipEvent_t get_event(slicer_handle h)
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;  // the scope below then skips timing for this launch
     return e;
 }
 
@@ -165,12 +175,21 @@ struct ProfScope {
         if (h->profiling) {
             e0 = get_event(h);
             e1 = get_event(h);
-            (void)hipEventRecord(e0, h->stream);
+            if (!e0 || !e1) {  // hipEventCreate failed: leave this launch untimed rather than record on a null event
+                if (e0)
+                    h->ev_pool.push_back(e0);
+                if (e1)
+                    h->ev_pool.push_back(e1);
+                e0 = e1 = nullptr;
+                h->prof_event_failures++;
+            } else {
+                (void)hipEventRecord(e0, h->stream);
+            }
         }
     }
     ~ProfScope()
     {
-        if (h->profiling) {
+        if (e0 && e1) {
             (void)hipEventRecord(e1, h->stream);
             h->prof.push_back({name, e0, e1});
         }
@@ -202,6 +221,12 @@ float ceil_to_f32(double v)
 }
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+int env_int(const char *name, int dflt = 0)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
 
 int acc_kind(const slicer_plane_desc &d, bool has_mass)
 {
@@ -304,15 +329,13 @@ int prepare_type(slicer_handle h, int type, bool has_mass)
     if (shared) {
         if (!h->shared_seen) {
             if (!h->fixed_shared_set) {
+                // From the mass table alone, which every sub-file of a snapshot carries identically -- not from which
+                // types this particular file holds -- so that ranks owning different sub-files pick the same scale
+                // (their FIXED64 accumulators are summed as integers: slicer_plane_accumulators).
                 double mm = 0;
-                bool any_mass = false;
                 for (int t = 0; t < 6; t++)
-                    if (h->file.npart[t] > 0) {
-                        if (d.hydro && h->file.massarr[t] == 0)
-                            any_mass = true;
-                        mm = std::max(mm, h->file.massarr[t]);
-                    }
-                h->fixed_exp_shared = pick_fixed_exp(d, mm, any_mass);
+                    mm = std::max(mm, h->file.massarr[t]);
+                h->fixed_exp_shared = pick_fixed_exp(d, mm, d.hydro != 0);
                 h->fixed_shared_set = true;
             }
             for (int p = 0; p < d.n_planes; p++) {
@@ -392,9 +415,9 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
         for (int q = p + 1; q < d.n_planes; q++)
             if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
                 return false;
-    static const int env_s = getenv("SLICER_TILE_LOG2") ? atoi(getenv("SLICER_TILE_LOG2")) : 0;
-    static const int env_h = getenv("SLICER_TILE_H_LOG2") ? atoi(getenv("SLICER_TILE_H_LOG2")) : 0;
-    static const int env_b = getenv("SLICER_BIN_BATCH") ? atoi(getenv("SLICER_BIN_BATCH")) : 0;
+    // tuning / test knobs, read on every call so that a test can flip them inside one process
+    const int env_s = env_int("SLICER_TILE_LOG2"), env_h = env_int("SLICER_TILE_H_LOG2");
+    const int env_b = env_int("SLICER_BIN_BATCH");
     const bool wide = acc != kCountU32;  // every mode but the NGP counts keeps 8-byte cells in LDS
     int s = 7;  // log2 tile side
     auto tiles = [&](int sl) {
@@ -412,13 +435,16 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     G.ntx = (d.npix + (1 << G.tw_log2) - 1) >> G.tw_log2;
     G.nty = (d.npix + (1 << G.th_log2) - 1) >> G.th_log2;
     // units: whole planes while everything fits kUnitBins tiles, otherwise bands of tile rows (large maps)
-    static const int env_rows = getenv("SLICER_UNIT_ROWS") ? atoi(getenv("SLICER_UNIT_ROWS")) : 0;  // tests
+    const int env_rows = env_int("SLICER_UNIT_ROWS");  // tests
     const long tiles_plane = (long)G.ntx * G.nty;
     if (tiles_plane * d.n_planes <= kUnitBins && !env_rows) {
         G.units_per_plane = 1;
         G.rows_per_unit = G.nty;
     } else {
         G.rows_per_unit = env_rows ? std::min(env_rows, G.nty) : std::max(1, 2048 / G.ntx);
+        // at most kMaxUnits units per pass (a test override may ask for thinner bands than that allows)
+        const int max_upp = std::max(1, kMaxUnits / d.n_planes);
+        G.rows_per_unit = std::max(G.rows_per_unit, (G.nty + max_upp - 1) / max_upp);
         G.units_per_plane = (G.nty + G.rows_per_unit - 1) / G.rows_per_unit;
     }
     G.tiles_per_unit = G.rows_per_unit * G.ntx;
@@ -440,7 +466,7 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
 // store phases overlap the other's; SLICER_K3_PER_CU overrides (tuning knob)
 static int scatter_workgroups(slicer_handle h)
 {
-    static const int per_cu = getenv("SLICER_K3_PER_CU") ? std::max(1, atoi(getenv("SLICER_K3_PER_CU"))) : 2;
+    const int per_cu = std::max(1, env_int("SLICER_K3_PER_CU", 2));
     return h->num_cus * per_cu;
 }
 
@@ -475,11 +501,11 @@ int flush_pending(slicer_handle h)
 {
     if (h->pend.n == 0)
         return SLICER_OK;
-    const void *before = h->w_items.p;
-    int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles));
+    bool fresh = false;
+    int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles), &fresh);
     if (rc)
         return rc;
-    if (h->w_items.p != before) {  // fresh workspace: both work-item counters start at zero
+    if (fresh) {  // fresh workspace: both work-item counters start at zero
         HIPCHK(h, hipMemsetAsync(h->w_items.p, 0, 16, h->stream));
         h->items_epoch = 0;
     }
@@ -534,13 +560,19 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
                                           (const float *)h->w_urand.p, 1. / pw, pw, h->stream));
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));  // h_urand is reused by the next chunk
+        h->algo_mask |= 1 << 3;
         return SLICER_OK;
     }
     BinGeom G;
     bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G) &&
                   scatter_lds_bytes(G, has_mass) <= 160 * 1024 - 256;
+    if (!binned && d.algo == SLICER_ALGO_BINNED)
+        return fail(h, SLICER_ERR_UNSUPPORTED,
+                    "SLICER_ALGO_BINNED cannot serve this pass (overlapping slabs, too many tile bins for one pass, or a "
+                    "tile table beyond the LDS limit); SLICER_ALGO_AUTO falls back to the fused global-atomic kernel");
     if (binned && d.algo == SLICER_ALGO_AUTO && n < 65536)
         binned = false;  // several launches are not worth it for a tiny chunk
+    h->algo_mask |= 1 << (binned ? SLICER_ALGO_BINNED : SLICER_ALGO_DIRECT);
     if (!binned) {
         ProfScope ps(h, KN_DIRECT);
         P.series_max = kSeriesMax15;  // no pre-test on this path: entries far outside the field reach project()
@@ -781,6 +813,8 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     h->finalized = false;
     h->shared_seen = false;
     h->fixed_shared_set = false;
+    h->algo_mask = 0;
+    h->neg_remote = false;
     h->pend.n = 0;
     h->pend_key = -1;
     h->pend_particles = 0;
@@ -1046,6 +1080,186 @@ int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts)
     return SLICER_OK;
 }
 
+int slicer_plane_algo_mask(slicer_handle h, int32_t *mask)
+{
+    if (!h || !mask)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    *mask = h->algo_mask;
+    return SLICER_OK;
+}
+
+int slicer_plane_status(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_status outside a plane pass");
+    HIPCHK(h, hipSetDevice(h->device));
+    int neg = 0;
+    HIPCHK(h, hipMemcpyAsync(&neg, h->d_neg, sizeof neg, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (neg || h->neg_remote)
+        return fail(h, SLICER_ERR_NEGATIVE_COORD,
+                    "a transformed coordinate is negative (positions outside [0, 2*boxsize]?): the reference stops "
+                    "here (densitymaps.cpp:334-345)%s", neg ? "" : " [reported by another rank]");
+    return SLICER_OK;
+}
+
+int slicer_plane_flush(slicer_handle h)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (!h->in_plane || h->in_file)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_flush: needs an open plane pass and no open file");
+    if (h->finalized)
+        return fail(h, SLICER_ERR_STATE, "slicer_plane_flush after slicer_plane_finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    return flush_pending(h);
+}
+
+namespace {
+// which accumulator slots (types 0..5, 6 = shared / all-types) take part in a cross-rank sum, and their element kind
+void reduce_slots(slicer_handle h, bool live[7], int &elem)
+{
+    const slicer_plane_desc &d = h->desc;
+    for (int s = 0; s < 7; s++)
+        live[s] = false;
+    if (d.mas == SLICER_MAS_NGP) {
+        // the per-file fold (densitymaps.cpp:511-513) already produced f32 maps: they are what the reference sums
+        elem = SLICER_ELEM_F32;
+        live[6] = true;
+        if (d.want_type_maps)
+            for (int t = 0; t < 6; t++)
+                live[t] = h->type_seen[t];
+        return;
+    }
+    elem = d.accum == SLICER_ACC_F64 ? SLICER_ELEM_F64 : d.accum == SLICER_ACC_FIXED64 ? SLICER_ELEM_FIXED64 : SLICER_ELEM_F32;
+    if (!d.want_type_maps) {
+        live[6] = h->shared_seen;
+        return;
+    }
+    for (int t = 0; t < 6; t++)
+        live[t] = h->type_seen[t];
+}
+}  // namespace
+
+int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m)
+{
+    if (!h || !m)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (!h->in_plane || h->in_file || h->finalized)
+        return fail(h, SLICER_ERR_STATE, "slicer_reduce_meta_get: after the last slicer_file_end, before finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = flush_pending(h);
+    if (rc)
+        return rc;
+    bool live[7];
+    int elem;
+    reduce_slots(h, live, elem);
+    for (int s = 0; s < 7; s++) {
+        m->v[s] = live[s] ? 1 : 0;
+        const bool fx = live[s] && elem == SLICER_ELEM_FIXED64;
+        const int e = s < 6 ? h->fixed_exp[s] : h->fixed_exp_shared;
+        m->v[7 + s] = fx ? e : INT32_MIN;
+        m->v[14 + s] = fx ? -e : INT32_MIN;
+    }
+    int neg = 0;
+    HIPCHK(h, hipMemcpyAsync(&neg, h->d_neg, sizeof neg, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    m->v[21] = neg ? 1 : 0;
+    m->v[22] = m->v[23] = 0;
+    return SLICER_OK;
+}
+
+int slicer_reduce_meta_set(slicer_handle h, const slicer_reduce_meta *m)
+{
+    if (!h || !m)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (!h->in_plane || h->in_file || h->finalized)
+        return fail(h, SLICER_ERR_STATE, "slicer_reduce_meta_set: after the last slicer_file_end, before finalize");
+    HIPCHK(h, hipSetDevice(h->device));
+    const slicer_plane_desc &d = h->desc;
+    bool live[7];
+    int elem;
+    reduce_slots(h, live, elem);
+    const bool ngp = d.mas == SLICER_MAS_NGP;
+    const size_t esz = elem == SLICER_ELEM_F32 ? 4 : 8;
+    for (int s = 0; s < 7; s++) {
+        if (!m->v[s])
+            continue;
+        if (elem == SLICER_ELEM_FIXED64) {
+            if (m->v[7 + s] == INT32_MIN || m->v[7 + s] != -m->v[14 + s])
+                return fail(h, SLICER_ERR_UNSUPPORTED,
+                            "ranks scaled FIXED64 accumulator %d differently (2^%d vs 2^%d): their integer sums cannot be "
+                            "added; pass the same mass table on every rank", s, m->v[7 + s], -m->v[14 + s]);
+            if (live[s] && (s < 6 ? h->fixed_exp[s] : h->fixed_exp_shared) != m->v[7 + s])
+                return fail(h, SLICER_ERR_UNSUPPORTED, "FIXED64 scale of accumulator %d differs from the combined one", s);
+        }
+        if (live[s])
+            continue;
+        // this rank never saw the slot: zero-filled stand-ins keep the set of collectives rank-invariant
+        const bool shared_layout = !ngp && !d.want_type_maps;
+        const bool valid = s == 6 ? shared_layout : (ngp ? d.want_type_maps != 0 : !shared_layout);
+        if (!valid)
+            return fail(h, SLICER_ERR_ARG, "combined reduce meta names accumulator %d, which this pass layout lacks", s);
+        for (int p = 0; p < d.n_planes; p++) {
+            int rc;
+            if (s == 6) {  // shared TSC accumulator (NGP's slot 6 is tot: always live)
+                if ((rc = ensure(h, h->planes[p].acc_shared, h->npix2 * esz)) ||
+                    (rc = zero_async(h, h->planes[p].acc_shared.p, h->npix2 * esz)))
+                    return rc;
+            } else {
+                if ((rc = ensure(h, h->planes[p].toti[s], h->npix2 * 4)) ||
+                    (rc = zero_async(h, h->planes[p].toti[s].p, h->npix2 * 4)))
+                    return rc;
+                if (!ngp && elem != SLICER_ELEM_F32 &&
+                    ((rc = ensure(h, h->planes[p].acc[s], h->npix2 * esz)) ||
+                     (rc = zero_async(h, h->planes[p].acc[s].p, h->npix2 * esz))))
+                    return rc;
+            }
+        }
+        if (s == 6) {
+            h->shared_seen = true;
+            h->fixed_exp_shared = elem == SLICER_ELEM_FIXED64 ? m->v[7 + s] : h->fixed_exp_shared;
+            h->fixed_shared_set = true;
+        } else {
+            h->type_seen[s] = true;
+            if (elem == SLICER_ELEM_FIXED64)
+                h->fixed_exp[s] = m->v[7 + s];
+            h->fixed_exp_set[s] = true;
+        }
+    }
+    h->neg_remote = m->v[21] != 0;
+    return SLICER_OK;
+}
+
+int slicer_plane_accumulators(slicer_handle h, int plane, void **acc, int32_t *elem_kind)
+{
+    if (!h || !acc || !elem_kind)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (!h->in_plane || h->in_file || h->finalized)
+        return fail(h, SLICER_ERR_STATE, "accumulators are available after the last slicer_file_end, before finalize");
+    if (plane < 0 || plane >= h->desc.n_planes)
+        return fail(h, SLICER_ERR_ARG, "plane %d out of range", plane);
+    if (h->pend.n)
+        return fail(h, SLICER_ERR_STATE, "call slicer_plane_flush (or slicer_reduce_meta_get) first");
+    bool live[7];
+    int elem;
+    reduce_slots(h, live, elem);
+    const bool ngp = h->desc.mas == SLICER_MAS_NGP;
+    for (int s = 0; s < 7; s++) {
+        acc[s] = nullptr;
+        if (!live[s])
+            continue;
+        if (s == 6)
+            acc[s] = ngp ? h->planes[plane].tot.p : h->planes[plane].acc_shared.p;
+        else
+            acc[s] = (ngp || elem == SLICER_ELEM_F32) ? h->planes[plane].toti[s].p : h->planes[plane].acc[s].p;
+    }
+    *elem_kind = elem;
+    return SLICER_OK;
+}
+
 int slicer_synchronize(slicer_handle h)
 {
     if (!h)
@@ -1065,13 +1279,9 @@ int slicer_plane_read(slicer_handle h, int plane, float *tot, float *toti, int64
     int rc = slicer_plane_finalize(h);
     if (rc)
         return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    int neg = 0;
-    HIPCHK(h, hipMemcpy(&neg, h->d_neg, sizeof neg, hipMemcpyDeviceToHost));
-    if (neg)
-        return fail(h, SLICER_ERR_NEGATIVE_COORD,
-                    "a transformed coordinate is negative (positions outside [0, 2*boxsize]?): the reference stops "
-                    "here (densitymaps.cpp:334-345)");
+    rc = slicer_plane_status(h);  // synchronises; densitymaps.cpp:334-345
+    if (rc)
+        return rc;
     const size_t n4 = h->npix2 * 4;
     if (tot)
         HIPCHK(h, hipMemcpy(tot, h->planes[plane].tot.p, n4, hipMemcpyDeviceToHost));
@@ -1105,6 +1315,7 @@ int slicer_device_free(slicer_handle h, void *d_ptr)
 {
     if (!h)
         return fail(h, SLICER_ERR_ARG, "null handle");
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipFree(d_ptr));
     return SLICER_OK;
 }

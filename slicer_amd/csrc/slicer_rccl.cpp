@@ -12,6 +12,7 @@ struct slicer_rccl_comm_s {
     ncclComm_t comm;
     int device;
     int nranks;
+    int32_t *d_meta = nullptr;  // device scratch of the reduce-meta all-reduce
 };
 
 namespace {
@@ -77,6 +78,10 @@ int slicer_rccl_comm_destroy(slicer_rccl_comm c)
 {
     if (!c)
         return SLICER_OK;
+    if (c->d_meta) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->d_meta);
+    }
     ncclCommDestroy(c->comm);
     delete c;
     return SLICER_OK;
@@ -84,33 +89,56 @@ int slicer_rccl_comm_destroy(slicer_rccl_comm c)
 
 int slicer_rccl_plane_reduce(slicer_handle h, slicer_rccl_comm c, int root, int per_type)
 {
+    (void)per_type;  // kept for source compatibility: the live accumulators decide what is summed
     if (!h || !c)
         return fail("slicer_rccl_plane_reduce", "null argument");
     void *sp = nullptr;
     if (slicer_get_stream(h, &sp) != SLICER_OK)
         return fail("slicer_get_stream", slicer_last_error(h));
     hipStream_t stream = (hipStream_t)sp;
-    if (slicer_plane_finalize(h) != SLICER_OK)
-        return fail("slicer_plane_finalize", slicer_last_error(h));
+    if (hipSetDevice(c->device) != hipSuccess)
+        return fail("hipSetDevice", hipGetErrorString(hipGetLastError()));
     int32_t npix = 0, n_planes = 0;
     if (slicer_plane_info(h, &npix, &n_planes) != SLICER_OK)
         return fail("slicer_plane_info", slicer_last_error(h));
+
+    // 1. make the set of collectives rank-invariant: element-wise MAX of the reduce meta (which accumulators are
+    //    live anywhere, their FIXED64 scales, the negativity guard), then zero-filled stand-ins where this rank has none
+    slicer_reduce_meta m;
+    if (slicer_reduce_meta_get(h, &m) != SLICER_OK)
+        return fail("slicer_reduce_meta_get", slicer_last_error(h));
+    if (!c->d_meta && hipMalloc((void **)&c->d_meta, sizeof m) != hipSuccess)
+        return fail("hipMalloc", hipGetErrorString(hipGetLastError()));
+    if (hipMemcpyAsync(c->d_meta, &m, sizeof m, hipMemcpyHostToDevice, stream) != hipSuccess)
+        return fail("hipMemcpyAsync", hipGetErrorString(hipGetLastError()));
+    NCCLCHK(ncclAllReduce(c->d_meta, c->d_meta, SLICER_REDUCE_META_INTS, ncclInt32, ncclMax, c->comm, stream));
+    if (hipMemcpyAsync(&m, c->d_meta, sizeof m, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return fail("meta all-reduce", hipGetErrorString(hipGetLastError()));
+    if (slicer_reduce_meta_set(h, &m) != SLICER_OK)
+        return fail("slicer_reduce_meta_set", slicer_last_error(h));
+
+    // 2. one rooted sum per live accumulator and plane, in the accumulator's own type (slicer-v2.cpp:214-217 sums
+    //    f32 maps; f64 / 64-bit fixed-point accumulators are summed before their single rounding to f32)
     const size_t n = (size_t)npix * (size_t)npix;
     for (int p = 0; p < n_planes; p++) {
-        float *tot = nullptr, *toti[6];
-        if (slicer_plane_device_maps(h, p, &tot, toti) != SLICER_OK)
-            return fail("slicer_plane_device_maps", slicer_last_error(h));
+        void *acc[7];
+        int32_t elem = 0;
+        if (slicer_plane_accumulators(h, p, acc, &elem) != SLICER_OK)
+            return fail("slicer_plane_accumulators", slicer_last_error(h));
+        const ncclDataType_t dt = elem == SLICER_ELEM_F64 ? ncclDouble : elem == SLICER_ELEM_FIXED64 ? ncclUint64 : ncclFloat;
         NCCLCHK(ncclGroupStart());
-        NCCLCHK(ncclReduce(tot, tot, n, ncclFloat, ncclSum, root, c->comm, stream));
-        if (per_type)
-            for (int t = 0; t < 6; t++)
-                if (toti[t])
-                    NCCLCHK(ncclReduce(toti[t], toti[t], n, ncclFloat, ncclSum, root, c->comm, stream));
+        for (int s = 0; s < 7; s++)
+            if (acc[s])
+                NCCLCHK(ncclReduce(acc[s], acc[s], n, dt, ncclSum, root, c->comm, stream));
         uint64_t *cnt = nullptr;
         if (slicer_plane_device_counts(h, p, &cnt) == SLICER_OK)
             NCCLCHK(ncclReduce(cnt, cnt, 6, ncclUint64, ncclSum, root, c->comm, stream));
         NCCLCHK(ncclGroupEnd());
     }
+    // 3. accumulators -> f32 maps (on the root these are the sums; elsewhere the rank's own partial maps)
+    if (slicer_plane_finalize(h) != SLICER_OK)
+        return fail("slicer_plane_finalize", slicer_last_error(h));
     return SLICER_OK;
 }
 

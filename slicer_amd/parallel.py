@@ -26,18 +26,53 @@ def device_tensor(torch, ptr, n, dtype="<f4"):
     return torch.as_tensor(o, device="cuda")
 
 
-def reduce_planes(S, dist, torch, root=0, per_type=False):
-    """Sum the finalized device maps of every plane of the current pass onto `root` (in place on root).
-    Replaces the MPI_Reduce calls of slicer-v2.cpp:214-217; per_type=False skips the six per-type maps
-    the reference reduces even when it never writes them (partinplanes == false)."""
+_ELEM_TYPESTR = {0: "<f4", 1: "<f8", 2: "<i8"}  # FIXED64 sums are integer sums mod 2^64: int64 adds the same bits
+
+
+def _as_tensor(torch, ref, n, elem):
+    """ref: a device pointer (int, memory owned by the slicer handle) or a host numpy array (CPU rehearsal)."""
+    if isinstance(ref, np.ndarray):
+        return torch.from_numpy(ref.reshape(-1).view(_ELEM_TYPESTR[elem]))
+    return device_tensor(torch, ref, n, _ELEM_TYPESTR[elem])
+
+
+def combine_meta(dist, torch, meta, on_device):
+    """Element-wise MAX of the 24-int reduce meta over all ranks (which accumulators are live anywhere, their
+    FIXED64 scales, the negativity guard): one small all-reduce that makes the later set of collectives rank-invariant."""
+    t = torch.tensor(meta, dtype=torch.int32, device="cuda" if on_device else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(x) for x in t.tolist()]
+
+
+def reduce_planes(S, dist, torch, root=0, per_type=None, async_op=False, finalize=True):
+    """Sum the current plane pass over the ranks onto `root`, in the accumulator's own type, then convert to f32 maps.
+
+    Replaces the MPI_Reduce calls of slicer-v2.cpp:214-217.  Call after the last file_end() and INSTEAD of
+    plane_finalize().  Every rank issues the same collectives even if its sub-files lack a particle type (zero-filled
+    stand-ins, as the reference reduces all seven maps unconditionally); f64 / fixed-point accumulators are summed
+    before their single rounding, so a FIXED64 N-rank result is bitwise the 1-rank result.
+    S: slicer_amd.Slicer, or any object with reduce_meta_get/set, plane_accumulators, plane_device_counts,
+    plane_finalize, npix, n_planes (the gloo rehearsal in tests/ uses a host stand-in).
+    async_op=True returns the pending works without finalizing: wait on them, then call S.plane_finalize()."""
+    del per_type  # the live accumulators decide (kept for source compatibility)
+    on_device = dist.get_backend() != "gloo"
+    S.reduce_meta_set(combine_meta(dist, torch, S.reduce_meta_get(), on_device))
     n = S.npix * S.npix
+    works = []
     for p in range(S.n_planes):
-        d_tot, d_toti = S.plane_device_maps(p)
-        dist.reduce(device_tensor(torch, d_tot, n), dst=root, op=dist.ReduceOp.SUM)
-        if per_type:
-            for t in range(6):
-                if d_toti[t]:
-                    dist.reduce(device_tensor(torch, d_toti[t], n), dst=root, op=dist.ReduceOp.SUM)
+        acc, elem = S.plane_accumulators(p)
+        for ref in acc:
+            if ref is not None:
+                works.append(dist.reduce(_as_tensor(torch, ref, n, elem), dst=root, op=dist.ReduceOp.SUM,
+                                         async_op=async_op))
+        cnt = S.plane_device_counts(p)
+        if cnt is not None:
+            works.append(dist.reduce(_as_tensor(torch, cnt, 6, 2), dst=root, op=dist.ReduceOp.SUM, async_op=async_op))
+    if async_op:
+        return works
+    if finalize:
+        S.plane_finalize()
+    return []
 
 
 def reduce_host_maps(dist, torch, maps, root=0):

@@ -43,7 +43,7 @@ def test_rccl_library_exports_its_header():
 
 def test_version_and_null_handle_errors():
     lib = _lib.load()
-    assert lib.slicer_version() == 100
+    assert lib.slicer_version() == 200
     assert lib.slicer_plane_begin(None, None) == 2  # SLICER_ERR_ARG, no crash
     assert lib.slicer_file_end(None) == 2
     assert b"null" in lib.slicer_last_error(None)

@@ -5,9 +5,12 @@ Bars:
   T-TSC  per-particle contributions are bit-identical; only summation order differs.  With k
          contributions c_j to a pixel, both the reference's sequential f32 sum and any f32 reordering
          are within (k-1)*2^-24*sum|c| of the exact sum, so |gpu - ref| <= 2*(k-1)*2^-24*ref*(1+eps).
-         We assert that deterministic bound per pixel AND an observed max-relative bar of 2e-6 (f32
-         atomics) / 1.2e-6 (f64 and fixed-point accumulators: what remains is the reference's own
-         sequential-f32 rounding noise, measured 5e-7..1e-6 in BASELINE.md S2).
+         We assert that deterministic bound per pixel AND SURVEY S8a's observed gate
+         max|d|/pixel <= max(1e-6, 2 * 2^-24 * sqrt(k_max)) (north_star's 1e-6 relative, widened only where a
+         pixel holds so many contributions that the reference's own sequential-f32 rounding noise exceeds it;
+         measured 3.5e-7..7e-7 for k_max 41..185).
+Every run that names an algorithm also asserts that THAT algorithm ran (slicer_plane_algo_mask): an explicit
+BINNED request never falls back to the fused global-atomic kernel silently.
 """
 import itertools
 
@@ -57,10 +60,18 @@ def run_gpu(S, files, npix, fov, ld, ld2, ngp=False, accum=slicer_amd.ACC_F32, a
                     S.deposit_host(t, pos[off:off + n], m)
             off += n
         S.file_end()
+    mask = S.algo_mask()
+    if algo != slicer_amd.ALGO_AUTO:
+        assert mask in (0, 1 << algo), f"asked for algorithm {algo}, mask of what ran = {mask:#x}"
     out = [S.plane_read(p, want_types=True) for p in range(len(ld))]
     for p in ptrs:
         S.free(p)
     return out
+
+
+def tsc_gate(kmax):
+    """SURVEY S8a T-TSC gate on the observed max relative pixel difference."""
+    return max(1e-6, 2.0 * U24 * np.sqrt(float(kmax)))
 
 
 def run_oracle(files, npix, fov, ld, ld2, ngp=False, nrep=0, hydro=False, rnd=RND):
@@ -78,7 +89,7 @@ def one_type_file(n, first=0, m=0.0123, t=1, clustered=False):
     return dict(npart=npart, massarr=massarr, boxsize=BOX, pos=synth.positions(first, n, BOX, clustered=clustered))
 
 
-def tsc_bound_check(gpu, ref, files, npix, fov, ld, ld2, nrep=0, rnd=RND, bar=2e-6):
+def tsc_bound_check(gpu, ref, files, npix, fov, ld, ld2, nrep=0, rnd=RND, bar=None):
     """Deterministic per-pixel bound + observed max-relative bar (one type-1 constant-mass file list)."""
     k = np.zeros((npix, npix), np.int64)
     for f in files:
@@ -91,6 +102,7 @@ def tsc_bound_check(gpu, ref, files, npix, fov, ld, ld2, nrep=0, rnd=RND, bar=2e
     assert np.all(d <= bound), f"per-pixel bound violated at {np.argwhere(d > bound)[:5]}"
     nz = ref > 0
     rel = float((d[nz] / ref[nz]).max())
+    bar = tsc_gate(int(k.max())) if bar is None else bar
     assert rel <= bar, f"max relative pixel error {rel:.3e} > {bar:.1e} (k_max={int(k.max())})"
     return rel, int(k.max())
 
@@ -284,8 +296,7 @@ def test_tsc_vs_oracle(S, npix, n, accum, algo):
     ref_tot, ref_toti, nsel = run_oracle(files, npix, fov, ld, ld2)
     (tot, toti, cnt), = run_gpu(S, files, npix, fov, ld, ld2, accum=accum, algo=algo)
     assert np.array_equal(cnt, nsel)
-    bar = 2e-6 if accum == slicer_amd.ACC_F32 else 1.2e-6
-    rel, kmax = tsc_bound_check(tot, ref_tot, files, npix, fov, ld, ld2, bar=bar)
+    rel, kmax = tsc_bound_check(tot, ref_tot, files, npix, fov, ld, ld2)
     assert np.array_equal(tot, toti[1])  # single species: mapxytot == mapxytoti[1] exactly
     print(f"TSC npix={npix} accum={accum} algo={algo}: max rel {rel:.2e}, k_max {kmax}")
 
@@ -366,15 +377,16 @@ def test_tsc_multi_type_multi_file(S, algo):
         # reproducible but accurate in the absolute sense, so pixels holding a single vanishing TSC weight
         # (<< 1e-6 m) get an absolute slack; f32 / f64 accumulators keep the purely relative bar.
         atol = 2.0 ** -29 if accum == slicer_amd.ACC_FIXED64 else 0.0
+        gate = tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2)  # S8a gate with k_max ~ 1.5 x the mean contributions per pixel
         for got, ref in [(tot, ref_tot)] + [(toti[t], ref_toti[t]) for t in range(6)]:
             if accum != slicer_amd.ACC_FIXED64:
                 assert np.array_equal(got == 0, ref == 0)
             d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-            assert np.all(d <= 3e-6 * ref + atol), float((d - 3e-6 * ref).max())
+            assert np.all(d <= gate * ref + atol), float((d - gate * ref).max())
         # shared accumulator (want_type_maps = 0) gives the same total within the same bar
         (tot2, _, _), = run_gpu(S, files, npix, fov, ld, ld2, accum=accum, algo=algo, want_type_maps=False)
         d = np.abs(tot2.astype(np.float64) - ref_tot.astype(np.float64))
-        assert np.all(d <= 3e-6 * ref_tot + atol)
+        assert np.all(d <= gate * ref_tot + atol)
 
 
 @pytest.mark.parametrize("npix", [128, 296])
@@ -452,7 +464,8 @@ def test_hydro_per_particle_masses_and_max_m_cap(S, algo):
             assert np.array_equal(toti[1].view(np.uint32), ref_toti[1].view(np.uint32))
         for got, ref in ((tot, ref_tot), (toti[0], ref_toti[0])):
             nz = ref > 0
-            assert float((np.abs(got[nz].astype(np.float64) - ref[nz]) / ref[nz]).max()) < 3e-6
+            assert float((np.abs(got[nz].astype(np.float64) - ref[nz]) / ref[nz]).max()) < tsc_gate(
+                1.5 * 9 * nsel.sum() / npix ** 2)
 
 
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
@@ -558,7 +571,7 @@ def test_baseline_config0_128cubed_256_ngp_bit_exact(S):
 
 def test_baseline_config1_256cubed_1024_tsc_four_planes(S):
     """BASELINE.json configs[1]: 256^3 particles, 1024^2 TSC, one snapshot -> 4 lens planes in one pass, every
-    plane against the oracle's createDensityMaps for that plane (per-pixel relative bar 2e-6, counts exact)."""
+    plane against the oracle's createDensityMaps for that plane (per-pixel relative gate of S8a, counts exact)."""
     n = 256 ** 3
     f = one_type_file(n)
     lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
@@ -572,7 +585,7 @@ def test_baseline_config1_256cubed_1024_tsc_four_planes(S):
         nz = ref_tot > 0
         rel = float((np.abs(tot[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max())
         worst = max(worst, rel)
-    assert worst <= 2e-6, worst
+    assert worst <= tsc_gate(1.5 * 9 * n * 0.2 / 1024 ** 2), worst
     print(f"config1: max per-pixel relative difference {worst:.2e}")
 
 
@@ -618,15 +631,16 @@ def test_golden_vectors(S, name, algo):
         else:
             assert np.array_equal(got == 0, ref == 0)
             d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-            assert np.all(d <= 2e-6 * ref)
+            assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / c["npix"] ** 2) * ref)
     if c["ngp"] and c["hydro"]:  # constant-mass species stay bit-exact under NGP even in a hydro run
         for t in (1, 2, 3, 5):
             assert np.array_equal(g_toti[t].view(np.uint32), toti[t].view(np.uint32))
 
 
 def test_large_maps_8192_ngp_exact_and_16384_properties(S):
-    """BASELINE configs[4] shape (16384^2): more than 8192 (plane, tile) bins, so the deposit takes the fused
-    global-atomic kernel; 8192^2 still runs the binned path.  NGP at 8192^2 is compared bit for bit with the
+    """BASELINE configs[4] shape (16384^2): more than 8192 (plane, tile) bins, so every plane is split into units of a
+    few tile rows (BinGeom) and the binned path still runs -- asserted through slicer_plane_algo_mask; 8192^2 runs it
+    with whole-plane units.  NGP at 8192^2 is compared bit for bit with the
     oracle; at 16384^2 (1 GiB per map) the checks are size-independent: counts equal the 8192^2 run's (the
     selection does not depend on npix beyond the 1-pixel FOV margin), integer NGP mass, TSC mass conservation."""
     n = 200000
@@ -636,6 +650,7 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S):
     S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
     S.deposit_host(1, f["pos"])
     S.file_end()
+    assert S.algo_mask() == 1 << slicer_amd.ALGO_BINNED
     tot, _, cnt = S.plane_read(0, want_types=False)
     assert np.array_equal(cnt, nsel)
     assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
@@ -645,6 +660,7 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S):
         S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
         S.deposit_host(1, f["pos"])
         S.file_end()
+        assert S.algo_mask() == 1 << slicer_amd.ALGO_BINNED
         big, _, cnt16 = S.plane_read(0, want_types=False)
         total = float(big.sum(dtype=np.float64))
         assert abs(int(cnt16[1]) - int(nsel[1])) <= 0.001 * nsel[1]
@@ -698,22 +714,28 @@ def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
         else:
             assert np.array_equal(tot == 0, ref_tot == 0)
             d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
-            assert np.all(d <= 3e-6 * ref_tot)
+            assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
 
 
 @pytest.mark.parametrize("rows", [1, 3])
-def test_band_units_layout_on_small_maps(rows):
+def test_band_units_layout_on_small_maps(S, rows, monkeypatch):
     """Large maps split every plane into units of a few tile rows (more than 8192 (plane, tile) bins).  The
-    SLICER_UNIT_ROWS override forces that layout on 512^2 / 1000^2 maps in a fresh process, where NGP can be
-    compared bit for bit with the oracle and fixed-point TSC with the fused kernel."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, SLICER_UNIT_ROWS=str(rows))
-    r = subprocess.run([sys.executable, os.path.join(here, "unit_rows_probe.py")], capture_output=True, text=True,
-                       env=env, timeout=600)
-    assert r.returncode == 0 and "unit-rows probe ok" in r.stdout, r.stderr[-1500:]
+    SLICER_UNIT_ROWS override (read on every call) forces that layout on 512^2 / 1000^2 maps, where NGP can be compared
+    bit for bit with the oracle and fixed-point TSC with the fused kernel; every binned run asserts that it ran binned."""
+    monkeypatch.setenv("SLICER_UNIT_ROWS", str(rows))
+    n = 300000
+    f = one_type_file(n, clustered=True)
+    for npix in (512, 1000):
+        lds, ld2s = [3.0, 3.5], [3.5, 4.0]
+        out = run_gpu(S, [f], npix, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, want_type_maps=False)
+        for p in range(2):
+            tot, _, nsel = run_oracle([f], npix, 0.25, lds[p], ld2s[p], ngp=True)
+            assert np.array_equal(out[p][2], nsel)
+            assert np.array_equal(out[p][0].view(np.uint32), tot.view(np.uint32)), (npix, p)
+        a = run_gpu(S, [f], npix, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_DIRECT)
+        b = run_gpu(S, [f], npix, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_BINNED)
+        for p in range(2):
+            assert np.array_equal(a[p][0].view(np.uint32), b[p][0].view(np.uint32)), (npix, p)
 
 
 def test_rccl_plane_reduce_single_rank(S):
@@ -736,3 +758,67 @@ def test_rccl_plane_reduce_single_rank(S):
     tot, toti, cnt = S.plane_read(0)
     assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32)) and np.array_equal(cnt, nsel)
     R.slicer_rccl_comm_destroy(comm)
+
+
+def test_explicit_binned_request_fails_loudly_when_unsupported(S):
+    """SLICER_ALGO_BINNED on a geometry the binned path cannot serve (overlapping slabs) returns
+    SLICER_ERR_UNSUPPORTED instead of silently running the 18x slower fused kernel; AUTO falls back and says so."""
+    f = one_type_file(100000)
+    lds, ld2s = [3.0, 3.2], [3.5, 4.0]  # overlapping slabs: a particle can belong to two planes
+    S.plane_begin(64, 0.25, lds, ld2s, algo=slicer_amd.ALGO_BINNED)
+    S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    with pytest.raises(slicer_amd.SlicerError) as e:
+        S.deposit_host(1, f["pos"])
+    assert e.value.code == slicer_amd.api.ERR_UNSUPPORTED
+    out = run_gpu(S, [f], 64, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_AUTO)
+    assert S.algo_mask() == 1 << slicer_amd.ALGO_DIRECT
+    for p in range(2):
+        ref_tot, _, nsel = run_oracle([f], 64, 0.25, lds[p], ld2s[p], ngp=True)
+        assert np.array_equal(out[p][2], nsel) and np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32))
+
+
+@pytest.mark.parametrize("accum", [slicer_amd.ACC_F32, slicer_amd.ACC_FIXED64])
+def test_reduce_meta_stand_ins_and_scale_check(S, accum):
+    """The rank-invariant collective set (include/slicer_amd.h "cross-rank sum"): a combined meta naming a species this
+    rank never saw makes the handle allocate a zero-filled stand-in, so that it can issue the same reduces as its peers;
+    FIXED64 scales that disagree between ranks are refused."""
+    f = one_type_file(100000)
+    npix = 128
+    S.plane_begin(npix, 0.25, [3.0], [4.0], accum=accum, want_type_maps=True)
+    S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    S.deposit_host(1, f["pos"])
+    S.file_end()
+    m = S.reduce_meta_get()
+    assert m[:7] == [0, 1, 0, 0, 0, 0, 0] and m[21] == 0
+    fx = accum == slicer_amd.ACC_FIXED64
+    assert (m[8] == -m[15] and m[8] > 0) if fx else (m[8] == -2 ** 31)
+    acc, elem = S.plane_accumulators(0)
+    assert acc[1] and not acc[4] and elem == (slicer_amd.ELEM_FIXED64 if fx else slicer_amd.ELEM_F32)
+    comb = list(m)
+    comb[4] = 1                       # another rank holds stars
+    if fx:
+        comb[7 + 4], comb[14 + 4] = 44, -44
+    S.reduce_meta_set(comb)
+    acc, _ = S.plane_accumulators(0)
+    assert acc[1] and acc[4]
+    stand_in = S.to_host(acc[4], npix * npix, np.int64 if fx else np.float32)
+    assert not stand_in.any()
+    if fx:
+        bad = list(comb)
+        bad[14 + 1] = -(comb[7 + 1] - 1)  # a peer scaled slot 1 differently: MAX(-exp) disagrees with MAX(exp)
+        with pytest.raises(slicer_amd.SlicerError) as e:
+            S.reduce_meta_set(bad)
+        assert e.value.code == slicer_amd.api.ERR_UNSUPPORTED
+    tot, toti, cnt = S.plane_read(0)
+    assert not toti[4].any() and np.array_equal(tot, toti[1]) and cnt[1] > 0
+    # the guard flag of a peer reaches this rank's status
+    S.plane_begin(npix, 0.25, [3.0], [4.0], accum=accum, want_type_maps=True)
+    S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+    S.deposit_host(1, f["pos"][:1000])
+    S.file_end()
+    m = S.reduce_meta_get()
+    m[21] = 1
+    S.reduce_meta_set(m)
+    with pytest.raises(slicer_amd.SlicerError) as e:
+        S.plane_read(0)
+    assert e.value.code == 1

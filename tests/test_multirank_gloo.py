@@ -51,6 +51,90 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _files_with_missing_species(BOX=1000.0):
+    """4 sub-files; particle type 4 (stars) lives only in sub-file 0, so with 2 ranks (files 0-1 | 2-3) rank 1 never
+    sees it -- the case in which per-rank `if (seen[t])` collectives deadlock."""
+    from slicer_amd import synth
+    files, first = [], 0
+    for ff in range(4):
+        n1, n4 = 2500 + 13 * ff, (700 if ff == 0 else 0)
+        pos = synth.positions(first, n1 + n4, BOX)
+        first += n1 + n4
+        files.append(dict(npart=[0, n1, 0, 0, n4, 0], massarr=[0, 0.25, 0, 0, 0.0625, 0], boxsize=BOX, pos=pos))
+    return files
+
+
+def _worker_acc(rank, world, port, q):
+    """reduce_planes (the code path bench.py and the C RCCL wrapper follow) on host stand-ins of the handles."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from host_rank import HostRankPass
+    from slicer_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rnd = dict(sgn=(-1, 1, -1), face=3, center=(0.3, 0.6, 0.1), rcase=3.0)
+    files = _files_with_missing_species()
+    lo, hi = parallel.file_range(len(files), world, rank)
+    out = {}
+    for mode, wtm in (("fixed64", True), ("fixed64", False), ("f64", True), ("f32", True), ("f32", False), ("ngp", True),
+                      ("ngp", False)):
+        mine = HostRankPass(files[lo:hi], 32, 0.25, 3.0, 4.0, rnd, mode=mode, want_type_maps=wtm)
+        had_type4 = mine.acc[4] is not None
+        parallel.reduce_planes(mine, dist, torch, root=0)
+        assert mine.finalized
+        if rank == 0:
+            one = HostRankPass(files, 32, 0.25, 3.0, 4.0, rnd, mode=mode, want_type_maps=wtm)
+            tot, toti = mine.maps()
+            rtot, rtoti = one.maps()
+            if mode == "fixed64":  # integer sums: bitwise the single-rank result, accumulators and maps alike
+                ok = all((a is None) == (b is None) and (a is None or np.array_equal(a, b))
+                         for a, b in zip(mine.acc, one.acc))
+                ok = ok and np.array_equal(tot.view(np.uint32), rtot.view(np.uint32))
+                ok = ok and np.array_equal(toti.view(np.uint32), rtoti.view(np.uint32))
+            elif mode == "ngp":    # masses are powers of two: every f32 sum is exact, any order
+                ok = np.array_equal(tot, rtot) and np.array_equal(toti, rtoti)
+            else:
+                ok = np.allclose(tot, rtot, rtol=2e-6, atol=0) and np.allclose(toti, rtoti, rtol=2e-6, atol=0)
+            ok = ok and np.array_equal(mine.counts, one.counts)
+            if wtm:
+                ok = ok and float(rtoti[4].sum()) > 0 and np.allclose(toti[4], rtoti[4], rtol=2e-6, atol=0)
+            out[f"{mode}/{int(wtm)}"] = bool(ok)
+        else:
+            out[f"{mode}/{int(wtm)}"] = (not had_type4) if wtm else True  # rank 1 really lacked the species
+    # the negativity guard of any rank reaches the root
+    bad = dict(npart=[0, 4, 0, 0, 0, 0], massarr=[0, 0.25, 0, 0, 0, 0], boxsize=1000.0,
+               pos=np.full((4, 3), 2600.0 if rank == 1 else 500.0, np.float32))
+    g = HostRankPass([bad], 32, 0.25, 3.0, 4.0, dict(sgn=(-1, -1, -1), face=1, center=(0., 0., 0.), rcase=0.0),
+                     mode="f32")
+    parallel.reduce_planes(g, dist, torch, root=0)
+    out["neg"] = bool(g.neg_remote) and (g.neg == (1 if rank == 1 else 0))
+    dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_accumulator_typed_reduce_with_a_species_missing_on_one_rank():
+    """Rank-invariant collective set (no deadlock when rank 1's sub-files lack type 4), sums in the accumulator type
+    (FIXED64 2-rank == 1-rank bitwise), selected-particle counters summed, negativity guard propagated."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_acc, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert all(res[r].values()), (r, res[r])
+
+
 def test_file_partition_matches_reference_rule():
     from slicer_amd import parallel
     import oracle
