@@ -29,7 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BOX = 1000.0
-RND = dict(sgn=(-1, 1, -1), face=3, center=(0.3, 0.6, 0.1), rcase=3.0)
+# Random.x0/y0/z0 are rand()/float(RAND_MAX) in the reference (densitymaps.cpp:188-190): binary32 values stored in
+# doubles.  The S8d centre (0.3, 0.6, 0.1) is therefore used as the reference could produce it: rounded to binary32.
+_F32 = lambda v: float(__import__("numpy").float32(v))  # noqa: E731
+RND = dict(sgn=(-1, 1, -1), face=3, center=(_F32(0.3), _F32(0.6), _F32(0.1)), rcase=3.0)
 LDS = [3.0, 3.25, 3.5, 3.75]
 LD2S = [3.25, 3.5, 3.75, 4.0]
 FOV = 0.25

@@ -156,7 +156,8 @@ int slicer_plane_info(slicer_handle h, int32_t *npix, int32_t *n_planes); /* of 
 int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
 
 /* Which deposit algorithms ran since slicer_plane_begin: bit SLICER_ALGO_DIRECT, bit SLICER_ALGO_BINNED
- * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0). */
+ * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0); bits 4 / 5 tell which project+bin kernel the
+ * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip). */
 int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
 /* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
  * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */
@@ -206,9 +207,17 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
  * op 1: out = a / b    (same operand range; a may be 0)
  * op 2: out = asin(a)  small-angle series, |a| <= 0.3125      op 3: out = atan(a), |a| <= 0.3125
  * op 4 / 5: the 9-term variants of 2 / 3, |a| <= 0.155
+ * op 6 / 7: the raw hardware estimates v_rsq_f64(a), v_rcp_f64(a)      op 8 / 9: their one-step refinements
+ *           (rsqrt_fast / rcp_fast of the fast project+bin kernel: not correctly rounded, < 2^-48 relative)
  * Lets the tests compare these with correctly rounded host results bit by bit (densitymaps.cpp:382-384 uses
  * sqrt, /, asin, atan2 of libm). */
 int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n);
+
+/* debug: the exhaustive sweep that licenses the f32 form of r / box in the fast project+bin kernel.  For every one of
+ * the 2^31 non-negative binary32 values r whose fast quotient lies in the fast path's domain (0, or 2^-100..1) the
+ * device compares it with (float)((double)r / box); *n_bad = number of mismatches (0 = licensed), examples8 = bit
+ * patterns of up to eight offending r.  The library runs the same sweep once per handle and box size. */
+int slicer_debug_box_quotient(slicer_handle h, double box, uint32_t *n_bad, uint32_t *examples8);
 
 /* per-kernel HIP-event timing (off by default; adds two event records per launch) */
 int slicer_profile_enable(slicer_handle h, int on);

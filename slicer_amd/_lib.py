@@ -67,6 +67,7 @@ SYMBOLS = {
     "slicer_synth_positions": (C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64, C.c_int]),
     "slicer_debug_project": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "slicer_debug_box_quotient": (C.c_int, [_H, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "slicer_debug_math": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "slicer_profile_enable": (C.c_int, [_H, C.c_int]),
     "slicer_profile_reset": (C.c_int, [_H]),

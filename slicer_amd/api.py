@@ -269,6 +269,13 @@ class Slicer:
                 self.free(p)
         return cnt.value, xs, ys, pl, src
 
+    def debug_box_quotient(self, box):
+        """(number of mismatches, up to 8 offending r) of the exhaustive f32-quotient sweep for this box size."""
+        n = C.c_uint32()
+        ex = (C.c_uint32 * 8)()
+        self._chk(_L.slicer_debug_box_quotient(self._h, float(box), C.byref(n), ex))
+        return n.value, np.array(list(ex), np.uint32).view(np.float32)[:min(n.value, 8)]
+
     def debug_math(self, op, a, b=None):
         """Device sqrt (op 0), quotient (1), small-angle asin (2) / atan (3) of float64 arrays; see slicer_amd.h."""
         a = np.ascontiguousarray(a, np.float64)

@@ -19,271 +19,13 @@
 //                        shaped (row-contiguous) global atomic flush of the non-zero cells.
 //
 // Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
-#include "slicer_kernels.hpp"
+#include "slicer_binned_common.hpp"
 
 #pragma clang fp contract(off)
 
 namespace slicer {
 
-namespace {
-
-#ifndef SLICER_K1_BLOCK
-#define SLICER_K1_BLOCK 768
-#endif
-#ifndef SLICER_K1_WAVES_PER_SIMD
-#define SLICER_K1_WAVES_PER_SIMD 6
-#endif
-constexpr int kK1Block = SLICER_K1_BLOCK;  // project+bin workgroup: 12 waves, two workgroups per CU at 32768 particles each
-#ifndef SLICER_K1_PER_THREAD
-#define SLICER_K1_PER_THREAD 4
-#endif
-constexpr int kPerThread = SLICER_K1_PER_THREAD;  // particles per lane and round (4: three dwordx4 loads)
-constexpr int kRound = kK1Block * kPerThread;  // particles per round of one K1 workgroup
-
-#ifndef SLICER_LDS_BARRIER
-#define SLICER_LDS_BARRIER 1
-#endif
-__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
-
-template <typename T>
-__device__ __forceinline__ T dmin(T a, T b) { return a < b ? a : b; }
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory queue
-// (s_waitcnt vmcnt(0)), which stalls every wave on loads and stores that nothing behind the barrier depends on.
-// Use where the barrier protects LDS contents; register dependences on loaded values are tracked by the compiler.
-__device__ __forceinline__ void lds_barrier()
-{
-#if SLICER_LDS_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------
-// K1: project + bin
-//
-// Every wave runs on its own: it streams 256 particles per round (4 per lane, three dwordx4 loads, the next
-// round's loads issued before the current round is processed), transforms them, and pushes the survivors of
-// the slab / FOV pre-test onto a wave-private LDS stack (positions from ballot + popcount, no atomics).
-// Whenever the stack holds >= 64 entries the wave pops 64 and runs the fp64 projection on a full wave.
-// There is no workgroup barrier in the loop; waves only share the histogram and the output cursor.
-// ---------------------------------------------------------------------------------------------
-#ifndef SLICER_K1_PREFETCH
-#define SLICER_K1_PREFETCH 1
-#endif
-constexpr bool kPrefetch = SLICER_K1_PREFETCH != 0;
-constexpr int kWaves = kK1Block / 64;
-constexpr int kWaveQ = 64 * kPerThread + 64;  // stack capacity per wave: one round + a remainder < 64
-
-__device__ __forceinline__ void lds_fence()
-{
-    // LDS traffic of this wave is complete and the compiler may not move memory operations across
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-template <bool VEC>
-__device__ __forceinline__ void load_round(const float *__restrict__ pos, uint64_t i0, int nvalid,
-                                           float (&rx)[kPerThread], float (&ry)[kPerThread], float (&rz)[kPerThread])
-{
-    static_assert(kPerThread % 4 == 0, "four particles = three dwordx4 loads");
-    if (VEC && nvalid == kPerThread) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
-#pragma unroll
-        for (int g = 0; g < kPerThread / 4; g++) {
-            const float4 a = p4[3 * g], b = p4[3 * g + 1], c = p4[3 * g + 2];
-            rx[4 * g + 0] = a.x; ry[4 * g + 0] = a.y; rz[4 * g + 0] = a.z;
-            rx[4 * g + 1] = a.w; ry[4 * g + 1] = b.x; rz[4 * g + 1] = b.y;
-            rx[4 * g + 2] = b.z; ry[4 * g + 2] = b.w; rz[4 * g + 2] = c.x;
-            rx[4 * g + 3] = c.y; ry[4 * g + 3] = c.z; rz[4 * g + 3] = c.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            if (k < nvalid) {
-                rx[k] = pos[3 * (i0 + k) + 0];
-                ry[k] = pos[3 * (i0 + k) + 1];
-                rz[k] = pos[3 * (i0 + k) + 2];
-            } else {
-                rx[k] = ry[k] = rz[k] = 0.f;
-            }
-        }
-    }
-}
-
-template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
-__global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin(const float *__restrict__ pos, const float *__restrict__ mass,
-                                                        uint64_t n, PassParams P, BinGeom G,
-                                                        float2 *__restrict__ cxy, unsigned short *__restrict__ cbin,
-                                                        float *__restrict__ cm, unsigned *__restrict__ hist16,
-                                                        unsigned *__restrict__ bcount, Targets T)
-{
-    extern __shared__ unsigned smem[];
-    // per-workgroup histogram, two 16-bit counters per word (a workgroup emits <= batch <= 65535 records)
-    unsigned *s_hist = smem;  // [hist_words]
-    const int hist_words = (G.nbins + 1) >> 1;
-    const int tid = threadIdx.x;
-    const unsigned lane = lane_id();
-    const int wave = tid >> 6;
-    // wave-private stack of float4 {x, y, z, plane | index-in-batch << 3}: one ds_write_b128 per push.  Per-particle
-    // masses are not carried along: the projection stage fetches the mass of a selected entry by that index.
-    float4 *q4 = reinterpret_cast<float4 *>(smem + ((hist_words + 3) & ~3)) + (size_t)wave * kWaveQ;
-    __shared__ unsigned s_out[kMaxUnits], s_cnt[kMaxPlanes];
-    __shared__ int s_neg;
-
-    for (int i = tid; i < hist_words; i += kK1Block)
-        s_hist[i] = 0;
-    if (tid < kMaxPlanes)
-        s_cnt[tid] = 0;
-    if (tid < kMaxUnits)
-        s_out[tid] = 0;
-    if (tid == 0)
-        s_neg = 0;
-    __syncthreads();
-
-    const uint64_t b0 = (uint64_t)blockIdx.x * G.batch;
-    const uint64_t b1 = dmin<uint64_t>(n, b0 + G.batch);
-    bool neg = false;
-    unsigned top = 0;  // entries on this wave's stack (wave-uniform)
-
-    // round r of this wave covers particles [w0 + r*kRound, +256): lane l owns 4 consecutive ones
-    const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
-    float rx[kPerThread], ry[kPerThread], rz[kPerThread];
-    float nx[kPerThread], ny[kPerThread], nz[kPerThread];
-    uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
-    int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
-    load_round<VEC>(pos, i0, nvalid, rx, ry, rz);
-
-    for (uint64_t r0 = w0; r0 < b1; r0 += kRound) {
-        // prefetch the next round while this one is processed
-        const uint64_t i1 = i0 + kRound;
-        const bool more = r0 + kRound < b1;
-        const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
-        if (kPrefetch && more)
-            load_round<VEC>(pos, i1, nvalid1, nx, ny, nz);
-
-        // ---- transform, slab select, conservative FOV pre-test, push ----
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            float x, y, z;
-            transform(rx[k], ry[k], rz[k], P, x, y, z);
-            const bool live = k < nvalid;
-            neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
-            // slabs are disjoint on this path (checked on the host); constant indices keep the thresholds in
-            // SGPRs, unused slots are empty intervals; the common <= 4-plane case tests half of them
-            int plane = -1;
-            if (P.n_planes <= 4) {
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-                    if (z >= P.zlo[p] && z < P.zhi[p])
-                        plane = p;
-            } else {
-#pragma unroll
-                for (int p = 0; p < kMaxPlanes; p++)
-                    if (z >= P.zlo[p] && z < P.zhi[p])
-                        plane = p;
-            }
-            // entries that certainly fail the FOV cut never reach the fp64 projection
-            const bool sel = live && plane >= 0 && !surely_outside_fov(x, y, z, P);
-            const unsigned long long mask = __ballot(sel);
-            if (sel) {
-                const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                const unsigned tag = (unsigned)plane | (HAS_MASS ? (unsigned)(i0 + k - b0) << 3 : 0u);
-                q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
-            }
-            top += (unsigned)__popcll(mask);
-        }
-        lds_fence();
-
-        // ---- fp64 projection on full waves popped from the stack ----
-        while (top >= 64u || (!more && top > 0u)) {
-            const unsigned take = top >= 64u ? 64u : top;
-            const unsigned e = top - take + lane;
-            bool emit = false, valid = false;
-            float xs = 0.f, ys = 0.f, m = 0.f;
-            unsigned bin = 0, unit = 0, tile_in_unit = 0;
-            int plane = 0;
-            if (lane < take) {
-                const float4 ent = q4[e];
-                plane = (int)(__float_as_uint(ent.w) & 7u);
-                if (project<SERIES>(ent.x, ent.y, ent.z, 0, 0, P, xs, ys)) {
-                    valid = true;
-                    int gx = grid_index<POW2>(xs, P);
-                    int gy = grid_index<POW2>(ys, P);
-                    const int nn = P.nn;
-                    if (MAS == kNGP) {
-                        emit = gx >= 0 && gx < nn && gy >= 0 && gy < nn;  // utilities.cpp:74 drop rule
-                    } else {
-                        emit = true;  // border-ring entries (g = -1 or nn) still feed the edge pixels
-                        gx = gx < 0 ? 0 : (gx >= nn ? nn - 1 : gx);
-                        gy = gy < 0 ? 0 : (gy >= nn ? nn - 1 : gy);
-                    }
-                    const unsigned ty = (unsigned)(gy >> G.th_log2), tx = (unsigned)(gx >> G.tw_log2);
-                    unsigned band = 0, trow = ty;
-                    if (G.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
-                        band = ty / (unsigned)G.rows_per_unit;
-                        trow = ty - band * (unsigned)G.rows_per_unit;
-                    }
-                    unit = (unsigned)plane * (unsigned)G.units_per_plane + band;
-                    tile_in_unit = trow * (unsigned)G.ntx + tx;
-                    bin = unit * (unsigned)G.tiles_per_unit + tile_in_unit;
-                    if (HAS_MASS)
-                        m = mass[b0 + (__float_as_uint(ent.w) >> 3)];
-                }
-            }
-            top -= take;
-            // selected-entry counters.  TSC emits every selected entry, so k_scan_bins takes them from the bin totals;
-            // NGP drops off-grid entries after selection and counts here: one LDS add per lane (the LDS pipe has slack)
-            if (MAS == kNGP && valid)
-                atomicAdd(&s_cnt[plane], 1u);
-            // Records go to the compact region of (unit, workgroup): [ (unit*gridDim.x + blockIdx.x) * batch, ... ).
-            unsigned o = 0;
-            // One returning LDS add per lane.  The LDS pipe serialises the lanes that share a unit, but it has slack
-            // in this kernel, while a loop over the wave's distinct units (one add by a leader lane, broadcasts, rank
-            // from ballots) cost the VALU -- the kernel's bound -- and a chain of LDS round trips: 175 -> 149 us.
-            if (emit)
-                o = atomicAdd(&s_out[unit], 1u);
-            if (emit) {
-                const uint64_t dst = ((uint64_t)unit * gridDim.x + blockIdx.x) * (uint64_t)G.batch + o;
-                cxy[dst] = make_float2(xs, ys);
-                cbin[dst] = (unsigned short)tile_in_unit;
-                if (HAS_MASS)
-                    cm[dst] = m;
-                atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
-            }
-        }
-        lds_fence();
-
-        // rotate the prefetched round in (or load it now)
-        if (kPrefetch) {
-#pragma unroll
-            for (int k = 0; k < kPerThread; k++) {
-                rx[k] = nx[k];
-                ry[k] = ny[k];
-                rz[k] = nz[k];
-            }
-        } else if (more) {
-            load_round<VEC>(pos, i1, nvalid1, rx, ry, rz);
-        }
-        i0 = i1;
-        nvalid = nvalid1;
-    }
-
-    if (neg)
-        s_neg = 1;
-    __syncthreads();
-    unsigned *row = hist16 + (size_t)blockIdx.x * hist_words;  // u16 [nbins] packed, row stride hist_words words
-    for (int i = tid; i < hist_words; i += kK1Block)
-        row[i] = s_hist[i];
-    if (tid < G.n_units)
-        bcount[(size_t)tid * gridDim.x + blockIdx.x] = s_out[tid];  // [unit][workgroup]
-    if (tid == 0 && s_neg)
-        atomicOr(T.neg_flag, 1);
-    if (MAS == kNGP && tid < P.n_planes && s_cnt[tid])
-        atomicAdd(T.nsel[tid], (unsigned long long)s_cnt[tid]);
-}
+// K1 (project + bin) lives in slicer_project_bin.hip.
 
 // ---------------------------------------------------------------------------------------------
 // K2a: per bin, exclusive prefix over workgroups + total: segment sums, a 32-way scan in LDS, prefix write.
@@ -427,9 +169,22 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s
     return off + x - v;
 }
 
+// The tile of a record is recomputed from (xs, ys) -- the same grid_index / clamp / tile arithmetic K1 used for its
+// histogram -- instead of being stored next to it: 2 bytes per record less to write and to read back, and this kernel
+// is bound by memory, not by instructions.
+__device__ __forceinline__ unsigned record_tile(float2 xy, int band, const GridParams &g, const BinGeom &G)
+{
+    int gx = grid_index_rt(xy.x, g), gy = grid_index_rt(xy.y, g);
+    // TSC records of the border ring were binned with the clamped cell; NGP records are always on the grid
+    gx = gx < 0 ? 0 : (gx >= g.nn ? g.nn - 1 : gx);
+    gy = gy < 0 ? 0 : (gy >= g.nn ? g.nn - 1 : gy);
+    const unsigned ty = (unsigned)(gy >> G.th_log2), tx = (unsigned)(gx >> G.tw_log2);
+    return (ty - (unsigned)band * (unsigned)G.rows_per_unit) * (unsigned)G.ntx + tx;
+}
+
 template <bool HAS_MASS>
 __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(const float2 *__restrict__ cxy,
-                                                            const unsigned short *__restrict__ cbin,
+                                                            GridParams grid,
                                                             const float *__restrict__ cm,
                                                             const unsigned *__restrict__ hist16w,
                                                             const unsigned *__restrict__ prefix,
@@ -473,7 +228,8 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
         const unsigned *brow = base + (size_t)plane * tpp;
         for (int i = tid; i < tpp; i += kSortBlock)
             cur[i] = brow[i] + row[i];
-        const uint64_t r0 = ((uint64_t)plane * nblocks + lb) * (uint64_t)G.batch;
+        const uint64_t r0 = ((uint64_t)plane * nblocks + lb) * (uint64_t)G.region;
+        const int band = plane % G.units_per_plane;  // `plane` is the unit index here
 
         // A region that fits one sub-batch (the usual case) needs no counting pass: its per-tile counts are this K1
         // workgroup's histogram row, already in the packed layout of cnt (needs the unit's first bin word-aligned).
@@ -492,8 +248,8 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
             for (int k = 0; k < R; k++) {
                 const unsigned i = (unsigned)k * kSortBlock + tid;
                 if (i < nsub) {
-                    tile[k] = cbin[r0 + s0 + i];
                     xy[k] = cxy[r0 + s0 + i];
+                    tile[k] = record_tile(xy[k], band, grid, G);
                     if (HAS_MASS)
                         m[k] = cm[r0 + s0 + i];
                     if (!single)
@@ -767,60 +523,6 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
-{
-    (void)has_mass;  // masses are fetched by index in the projection stage, not carried on the stacks
-    return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * 16;
-}
-
-template <int MAS, bool POW2, bool HAS_MASS, bool VEC, int SERIES>
-static hipError_t launch_k1_2(const float *pos, const float *mass, uint64_t n, const PassParams &P, const BinGeom &G,
-                              const BinWorkspace &W, const Targets &T, hipStream_t s)
-{
-    const int nb = (int)((n + G.batch - 1) / G.batch);
-    const size_t lds = project_bin_lds_bytes(G, HAS_MASS);
-    auto kern = k_project_bin<MAS, POW2, HAS_MASS, VEC, SERIES>;
-    if (lds > 48 * 1024) {  // up to 64 KiB of histogram + the wave stacks
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-    }
-    kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, P, G, W.cxy, reinterpret_cast<unsigned short *>(W.cbin), W.cm, W.hist16,
-                                   W.bcount, T);
-    return hipGetLastError();
-}
-
-template <int MAS, bool POW2, bool HAS_MASS>
-static hipError_t launch_k1(bool vec, const float *pos, const float *mass, uint64_t n, const PassParams &P,
-                            const BinGeom &G, const BinWorkspace &W, const Targets &T, hipStream_t s)
-{
-    const bool s9 = P.series_max < 0.2;  // every survivor of the pre-test is inside the 9-term range
-    if (vec)
-        return s9 ? launch_k1_2<MAS, POW2, HAS_MASS, true, 9>(pos, mass, n, P, G, W, T, s)
-                  : launch_k1_2<MAS, POW2, HAS_MASS, true, 15>(pos, mass, n, P, G, W, T, s);
-    return s9 ? launch_k1_2<MAS, POW2, HAS_MASS, false, 9>(pos, mass, n, P, G, W, T, s)
-              : launch_k1_2<MAS, POW2, HAS_MASS, false, 15>(pos, mass, n, P, G, W, T, s);
-}
-
-hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
-                              const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
-                              hipStream_t s)
-{
-    const bool vec = (reinterpret_cast<uintptr_t>(d_pos) & 15u) == 0;
-    const bool pow2 = P.pow2 != 0;
-#define K1(MAS_, P2_, HM_) launch_k1<MAS_, P2_, HM_>(vec, d_pos, d_mass, n, P, G, W, T, s)
-    if (cfg.mas == kNGP) {
-        if (pow2)
-            return cfg.has_mass ? K1(kNGP, true, true) : K1(kNGP, true, false);
-        return cfg.has_mass ? K1(kNGP, false, true) : K1(kNGP, false, false);
-    }
-    if (pow2)
-        return cfg.has_mass ? K1(kTSC, true, true) : K1(kTSC, true, false);
-    return cfg.has_mass ? K1(kTSC, false, true) : K1(kTSC, false, false);
-#undef K1
-}
-
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s)
 {
@@ -837,27 +539,32 @@ size_t scatter_lds_bytes(const BinGeom &G, bool has_mass)
     return 4 * (tw + 2 * tpp + (tw & 1)) + (size_t)kSortStage * (8 + 2 + (has_mass ? 4 : 0));
 }
 
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const BinGeom &G, const BinWorkspace &W,
-                              hipStream_t s)
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const PassParams &P, int mas,
+                              const BinGeom &G, const BinWorkspace &W, hipStream_t s)
 {
+    GridParams grid;
+    grid.nn = P.nn;
+    grid.pow2 = P.pow2;
+    grid.ngp = mas == kNGP;
+    grid.nn_f = P.nn_f;
+    grid.dl = P.dl;
     const size_t lds = scatter_lds_bytes(G, has_mass);
     const int items = G.n_units * 8 * ((nblocks + 7) / 8);
-    const int grid = std::min(items, std::max(8, max_workgroups / 8 * 8));
-    const unsigned short *cb = reinterpret_cast<const unsigned short *>(W.cbin);
+    const int nwg = std::min(items, std::max(8, max_workgroups / 8 * 8));
     hipError_t e;
     if (has_mass) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<true><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<true><<<nwg, kSortBlock, lds, s>>>(W.cxy, grid, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                           W.sm);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<false><<<grid, kSortBlock, lds, s>>>(W.cxy, cb, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
+        k_bin_scatter<false><<<nwg, kSortBlock, lds, s>>>(W.cxy, grid, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
                                                            W.sm);
     }
     return hipGetLastError();

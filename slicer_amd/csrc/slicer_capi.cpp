@@ -79,7 +79,11 @@ struct slicer_handle_s {
     uint64_t stage_cap = 0;  // particles
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
-    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    DevBuf w_cxy, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    // box sizes whose f32 quotient r/box passed (true) or failed (false) the exhaustive device sweep
+    // (launch_check_box_quotient): k_project_bin_fast is only used for the former
+    std::vector<std::pair<double, bool>> box_verdicts;
+    unsigned *d_sweep = nullptr;
     DevBuf w_tcounts, w_tbase, w_urand;  // shot-noise thinning (snopt > 0)
     std::vector<float> h_urand;
     uint64_t pend_particles = 0;  // particles behind the pending chunks (bounds their record count)
@@ -408,9 +412,12 @@ constexpr int kUnitBins = 8192;   // up to this many bins the units are whole pl
 // Small maps get smaller tiles so that the grid still has >= ~1024 workgroups.
 bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
 {
+    int nrmax = 0;
     for (int p = 0; p < d.n_planes; p++)
-        if (d.nrepperp[p] != 0)
-            return false;
+        nrmax = std::max(nrmax, d.nrepperp[p]);
+    if (nrmax > 3)  // (2n+1)^2 records per particle must fit the 16-bit per-workgroup counters at a 1024-particle batch
+        return false;
+    const int reps = (2 * nrmax + 1) * (2 * nrmax + 1);
     for (int p = 0; p < d.n_planes; p++)  // slabs must be disjoint: a particle enters at most one bin
         for (int q = p + 1; q < d.n_planes; q++)
             if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
@@ -457,6 +464,8 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     // workgroup's first particle 16-byte aligned (multiple of 4; kept at a multiple of 1024) and fit the 16-bit
     // per-workgroup counters
     G.batch = env_b ? std::min(std::max((env_b / 1024) * 1024, 1024), 64512) : kBinBatch;
+    G.batch = std::min(G.batch, std::max(1024, 65535 / reps / 1024 * 1024));  // lateral replicas multiply the records
+    G.region = G.batch * reps;
     if (G.tw_log2 < 3 || G.tw_log2 > 8 || G.th_log2 < 3 || G.th_log2 > 8)
         return false;
     return true;
@@ -470,21 +479,115 @@ static int scatter_workgroups(slicer_handle h)
     return h->num_cus * per_cu;
 }
 
+int run_box_sweep(slicer_handle h, double box, unsigned out[9])
+{
+    if (!h->d_sweep)
+        HIPCHK(h, hipMalloc((void **)&h->d_sweep, 9 * sizeof(unsigned)));
+    HIPCHK(h, hipMemsetAsync(h->d_sweep, 0, 9 * sizeof(unsigned), h->stream));
+    HIPCHK(h, launch_check_box_quotient(box, h->d_sweep, h->stream));
+    out[0] = 1;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sweep, 9 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLICER_OK;
+}
+
+// Has the f32 form of r / box (k_project_bin_fast) been proven for this box size?  One exhaustive device sweep over
+// all 2^31 non-negative floats per distinct box size and handle (a few milliseconds), then cached.
+int box_quotient_ok(slicer_handle h, double box, bool &ok)
+{
+    for (auto &v : h->box_verdicts)
+        if (v.first == box) {
+            ok = v.second;
+            return SLICER_OK;
+        }
+    unsigned out[9];
+    int rc = run_box_sweep(h, box, out);
+    if (rc)
+        return rc;
+    ok = out[0] == 0;
+    h->box_verdicts.emplace_back(box, ok);
+    return SLICER_OK;
+}
+
+// Kernel arguments of k_project_bin_fast and whether this (file, pass) qualifies for it; see the conditions in
+// slicer_project_bin.hip.  SLICER_K1_GENERAL=1 forces the general kernel (tests run both).
+int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nblocks, K1Args &A, bool &fast)
+{
+    memset(&A, 0, sizeof A);
+    fast = false;
+    if (env_int("SLICER_K1_GENERAL") || P.n_planes > 4 || !(P.lim < 1.5) || G.region != G.batch || !P.pow2 ||
+        (uint64_t)G.n_units * (uint64_t)nblocks * (uint64_t)G.region >= (1ull << 31))
+        return SLICER_OK;
+    for (int p = 0; p < P.n_planes; p++)
+        if (P.nrep[p] != 0)
+            return SLICER_OK;
+    for (int p = 0; p + 1 < P.n_planes; p++)  // consecutive slabs (the planes of one box replication)
+        if (!(P.zhi[p] == P.zlo[p + 1] && P.zlo[p] <= P.zhi[p]))
+            return SLICER_OK;
+    if (!(P.rcase >= 0.0f) || !std::isfinite(P.rcase) || !std::isfinite((float)P.box) || (float)P.box <= 0.0f)
+        return SLICER_OK;
+    for (int a = 0; a < 3; a++) {
+        const double c = P.c0[a];
+        // the recentring runs in f32: exact iff the centre is an f32 value (rand()/float(RAND_MAX) is one,
+        // densitymaps.cpp:188-190)
+        // (centres below 2^-20 -- e.g. the exact 0 of -DUSE_FIXED_PLC_VERTEX -- are where the reference's -0.0 and the
+        // last bit of a quotient below 2^-100 could reach the result: left to the general kernel)
+        if (!((double)(float)c == c) || !(c >= 0x1p-20 && c <= 1.0))
+            return SLICER_OK;
+    }
+    bool ok = false;
+    int rc = box_quotient_ok(h, P.box, ok);
+    if (rc)
+        return rc;
+    if (!ok)
+        return SLICER_OK;
+    A.boxf = (float)P.box;
+    A.rb = 1.0f / A.boxf;
+    for (int a = 0; a < 3; a++) {
+        const float sg = P.sgn[P.perm[a]];
+        A.ws[a] = sg;
+        A.wo[a] = sg < 0.0f ? 1.0f : 0.0f;
+        A.c0f[a] = (float)P.c0[a];
+    }
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
+    A.face = 0;
+    for (int f = 0; f < 6; f++)
+        if (perms[f][0] == P.perm[0] && perms[f][1] == P.perm[1] && perms[f][2] == P.perm[2])
+            A.face = f;
+    A.rcase = P.rcase;
+    A.n_planes = P.n_planes;
+    for (int p = 0; p < 4; p++)
+        A.zlo[p] = P.zlo[p];  // +inf beyond n_planes (make_params)
+    A.zlast = P.zhi[P.n_planes - 1];
+    const double tl = std::tan(P.lim);
+    A.k_ra = ceil_to_f32(tl * (1.0 + 3e-5));
+    A.eps_ra = 2e-6f;
+    A.k_dec = ceil_to_f32(tl * std::sqrt(1.0 + (double)A.k_ra * (double)A.k_ra) * (1.0 + 3e-5));
+    A.eps_dec = ceil_to_f32(tl * 2.2e-6 + 1e-6);
+    A.series_max = P.series_max;
+    A.lim = P.lim;
+    A.inv_fov = P.inv_fov;
+    A.nn_f = P.nn_f;
+    A.nn = P.nn;
+    fast = true;
+    return SLICER_OK;
+}
+
 int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, const BinGeom &G, BinWorkspace &W)
 {
     const uint64_t nb = (n + G.batch - 1) / G.batch;
-    const uint64_t region = (uint64_t)G.n_units * nb * G.batch;  // compact records: [unit][workgroup][batch]
+    const uint64_t region = (uint64_t)G.n_units * nb * G.region;  // compact records: [unit][workgroup][region]
+    const uint64_t nrec = n * (uint64_t)(G.region / G.batch);     // most records this chunk can emit
     int rc;
-    if ((rc = ensure(h, h->w_cxy, region * 8)) || (rc = ensure(h, h->w_cbin, region * 2)) ||
+    if ((rc = ensure(h, h->w_cxy, region * 8)) ||
         (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
         (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
-        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, h->w_sxy[slot], n * 8)) ||
+        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, h->w_sxy[slot], nrec * 8)) ||
         (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
-    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], n * 4))))
+    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], nrec * 4))))
         return rc;
     W.cxy = (float2 *)h->w_cxy.p;
-    W.cbin = (unsigned *)h->w_cbin.p;
     W.cm = (float *)h->w_cm.p;
     W.sxy = (float2 *)h->w_sxy[slot].p;
     W.sm = (float *)h->w_sm[slot].p;
@@ -585,7 +688,9 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         const uint64_t slots = 2ull * (uint64_t)h->num_cus;
         const uint64_t rounds = (n + slots * kBinBatch - 1) / (slots * kBinBatch);
         const uint64_t per = (n + slots * rounds - 1) / (slots * rounds);
-        G.batch = (int)std::min<uint64_t>(kBinBatch, std::max<uint64_t>(8192, (per + 1023) / 1024 * 1024));
+        const int reps = G.region / G.batch;
+        G.batch = (int)std::min<uint64_t>(G.batch, std::max<uint64_t>(std::min(8192, G.batch), (per + 1023) / 1024 * 1024));
+        G.region = G.batch * reps;
     }
     const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
     const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
@@ -597,9 +702,14 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     if ((rc = ensure_bin_workspace(h, has_mass, slot, n, G, W)))
         return rc;
     const int nblocks = (int)((n + G.batch - 1) / G.batch);
+    K1Args A;
+    bool fast = false;
+    if ((rc = k1_fast_args(h, P, G, nblocks, A, fast)))
+        return rc;
+    h->algo_mask |= fast ? (1 << 4) : (1 << 5);
     {
         ProfScope ps(h, KN_PROJECT);
-        HIPCHK(h, launch_project_bin(cfg, d_pos, d_mass, n, P, G, W, T, h->stream));
+        HIPCHK(h, launch_project_bin(cfg, fast, d_pos, d_mass, n, P, A, G, W, T, h->stream));
     }
     {
         ProfScope ps(h, KN_SCAN);
@@ -607,7 +717,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, scatter_workgroups(h), G, W, h->stream));
+        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, scatter_workgroups(h), P, cfg.mas, G, W, h->stream));
     }
     if (slot == 0) {
         h->pend_key = key;
@@ -622,7 +732,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     h->pend.mconst[slot] = P.mconst;
     h->pend.sm_const[slot] = P.sm_const;
     h->pend.n = slot + 1;
-    h->pend_particles += n;
+    h->pend_particles += n * (uint64_t)(G.region / G.batch);  // bounds the records behind the pending chunks
     return SLICER_OK;
 }
 
@@ -749,7 +859,9 @@ int slicer_destroy(slicer_handle h)
             release(pl.acc[t]);
         }
     }
-    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
+    if (h->d_sweep)
+        (void)hipFree(h->d_sweep);
+    for (DevBuf *b : {&h->w_cxy, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
                       &h->w_tcounts, &h->w_tbase, &h->w_urand})
         release(*b);
     for (int i = 0; i < kMaxPending; i++) {
@@ -1373,11 +1485,26 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
     return SLICER_OK;
 }
 
+int slicer_debug_box_quotient(slicer_handle h, double box, uint32_t *n_bad, uint32_t *examples8)
+{
+    if (!h || !n_bad)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned out[9];
+    int rc = run_box_sweep(h, box, out);
+    if (rc)
+        return rc;
+    *n_bad = out[0];
+    if (examples8)
+        memcpy(examples8, out + 1, 8 * sizeof(uint32_t));
+    return SLICER_OK;
+}
+
 int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n)
 {
     if (!h)
         return fail(h, SLICER_ERR_ARG, "null handle");
-    if (op < 0 || op > 5 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
+    if (op < 0 || op > 9 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
         return fail(h, SLICER_ERR_ARG, "slicer_debug_math: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, launch_debug_math(op, d_a, d_b, d_out, n, h->stream));

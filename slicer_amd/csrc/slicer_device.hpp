@@ -225,6 +225,26 @@ __device__ __forceinline__ double div_midrange(double n, double d)  // 2^-500 <=
     return fma(r, y, q0);
 }
 
+// ---- fast (not correctly rounded) reciprocal square root and reciprocal -------------------------------------------
+// One cubically convergent step on the hardware estimates (v_rsq_f64 / v_rcp_f64 are good to ~2^-20..2^-23; measured
+// by tests/test_gpu_parity.py::test_fast_projection_error_budget through slicer_debug_math ops 6-9):
+//   rsqrt: e = 1 - S y^2,  y <- y (1 + e/2 + 3 e^2/8)      error ~ e^3      5 instructions
+//   rcp:   e = 1 - d y,    y <- y (1 + e + e^2)            error ~ e^3      3 instructions
+// Used by k_project_bin_fast, whose results are only trusted where a 2^-41 window around them decides the rounding.
+__device__ __forceinline__ double rsqrt_fast(double S)
+{
+    const double y = __builtin_amdgcn_rsq(S);
+    const double e = fma(-(S * y), y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+__device__ __forceinline__ double rcp_fast(double d)
+{
+    const double y = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y, 1.0);
+    return fma(y, fma(e, e, e), y);
+}
+
 // (float)(ang / fov + 0.5)      densitymaps.cpp:385-386
 // s = RN64(ang * RN64(1/fov)) + 0.5 is within 2^-51 (absolute, |ang/fov| < 1) of the reference's f64 value, so its
 // rounding to f32 is the reference's unless s sits within 2^-50 of an f32 rounding tie.  The test is made cheap rather

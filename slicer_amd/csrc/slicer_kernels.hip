@@ -516,7 +516,11 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
     case 2: r = asin_small<15>(a[i]); break;
     case 3: r = atan_small<15>(a[i]); break;
     case 4: r = asin_small<9>(a[i]); break;
-    default: r = atan_small<9>(a[i]); break;
+    case 5: r = atan_small<9>(a[i]); break;
+    case 6: r = __builtin_amdgcn_rsq(a[i]); break;  // the raw hardware estimates ...
+    case 7: r = __builtin_amdgcn_rcp(a[i]); break;
+    case 8: r = rsqrt_fast(a[i]); break;            // ... and their one-step refinements (k_project_bin_fast)
+    default: r = rcp_fast(a[i]); break;
     }
     out[i] = r;
 }

@@ -76,14 +76,15 @@ struct BinGeom {
     int rows_per_unit;     // tile rows per unit
     int n_units;           // n_planes * units_per_plane (<= kMaxUnits)
     int nbins;             // n_units * tiles_per_unit; bin = unit * tiles_per_unit + tile_in_unit
-    int batch;             // particles per K1 workgroup (= size of its region in the compact buffer)
+    int batch;             // particles per K1 workgroup
+    int region;            // records a K1 workgroup may emit per unit = size of its region in the compact buffer:
+                           // batch * (2 nrepperp + 1)^2 (lateral replication, densitymaps.cpp:377-399), <= 65535
 };
 constexpr int kMaxUnits = 32;
 
 struct BinWorkspace {
-    float2 *cxy;       // [n_units][nblocks][batch] compact (xs, ys) of (unit, K1 workgroup), bcount[unit][b] valid
-    unsigned *cbin;    // same shape, u16 tile-in-unit of each compact record
-    float *cm;         // [max_chunk] per-particle mass (hydro) or nullptr
+    float2 *cxy;       // [n_units][nblocks][region] compact (xs, ys) of (unit, K1 workgroup), bcount[unit][b] valid
+    float *cm;         // same shape: per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
     float *sm;         // [max_chunk] or nullptr
     unsigned *hist16;  // [nblocks][ceil(nbins/2)] per-workgroup histogram, two u16 counters per word
@@ -93,16 +94,52 @@ struct BinWorkspace {
     unsigned *bcount;  // [n_units][nblocks]
 };
 
+// Kernel-argument block of k_project_bin_fast (slicer_project_bin.hip): only what its hot loop reads, so that the
+// uniform operands stay in SGPRs; the full PassParams rides along as a separate kernel argument for the exact paths.
+struct K1Args {
+    const float *pos;
+    const float *mass;         // per-particle masses or nullptr
+    uint64_t n;
+    float2 *cxy;
+    float *cm;
+    unsigned *hist16;
+    unsigned *bcount;
+    int *neg_flag;
+    unsigned long long *nsel;  // counter of plane 0 for this type; plane p at nsel + 6 p
+    // transform (gadget2io.cpp:204-270), per OUTPUT axis a (source axis perm[a]; the permutation itself is a template
+    // argument of the kernel, `face` selects the instantiation)
+    float rb, boxf;            // RN32(1 / box), (float)box
+    float ws[3], wo[3];        // first wrap as fma(q, ws, wo): (+1, 0) for sgn = +1, (-1, 1) for sgn = -1
+    float c0f[3];              // Random.x0 / y0 / z0: f32 values, as the reference draws them
+    float rcase;
+    int face;                  // Random.face - 1
+    // slabs (densitymaps.cpp:346-347,374) of consecutive planes: zlo[p] as in PassParams, +inf for p >= n_planes;
+    // zlast = zhi[n_planes - 1]
+    float zlo[4], zlast;
+    int n_planes, vec, ngp;
+    // conservative FOV pre-test
+    float k_ra, eps_ra, k_dec, eps_dec;
+    // projection + grid (power-of-two maps)
+    double series_max, lim, inv_fov;
+    float nn_f;
+    int nn;
+    // tile geometry (BinGeom)
+    int tw_log2, th_log2, ntx, tiles_per_unit, units_per_plane, rows_per_unit, n_units, nbins, batch;
+};
+
+// exhaustive device check of the f32 form of r / box used by k_project_bin_fast (all 2^31 non-negative floats)
+hipError_t launch_check_box_quotient(double box, unsigned *d_mismatches, hipStream_t s);
+
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
 size_t tile_lds_bytes(const BinGeom &G, int acc);
 size_t scatter_lds_bytes(const BinGeom &G, bool has_mass);
-hipError_t launch_project_bin(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
-                              const PassParams &P, const BinGeom &G, const BinWorkspace &W, const Targets &T,
-                              hipStream_t s);
+hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_pos, const float *d_mass, uint64_t n,
+                              const PassParams &P, const K1Args &A, const BinGeom &G, const BinWorkspace &W,
+                              const Targets &T, hipStream_t s);
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s);
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const BinGeom &G, const BinWorkspace &W,
-                              hipStream_t s);
+hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const PassParams &P, int mas,
+                              const BinGeom &G, const BinWorkspace &W, hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
 constexpr int kMaxPending = 8;

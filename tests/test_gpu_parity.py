@@ -62,7 +62,7 @@ def run_gpu(S, files, npix, fov, ld, ld2, ngp=False, accum=slicer_amd.ACC_F32, a
         S.file_end()
     mask = S.algo_mask()
     if algo != slicer_amd.ALGO_AUTO:
-        assert mask in (0, 1 << algo), f"asked for algorithm {algo}, mask of what ran = {mask:#x}"
+        assert (mask & 15) in (0, 1 << algo), f"asked for algorithm {algo}, mask of what ran = {mask:#x}"
     out = [S.plane_read(p, want_types=True) for p in range(len(ld))]
     for p in ptrs:
         S.free(p)
@@ -650,7 +650,7 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S):
     S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
     S.deposit_host(1, f["pos"])
     S.file_end()
-    assert S.algo_mask() == 1 << slicer_amd.ALGO_BINNED
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
     tot, _, cnt = S.plane_read(0, want_types=False)
     assert np.array_equal(cnt, nsel)
     assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
@@ -660,7 +660,7 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S):
         S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
         S.deposit_host(1, f["pos"])
         S.file_end()
-        assert S.algo_mask() == 1 << slicer_amd.ALGO_BINNED
+        assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
         big, _, cnt16 = S.plane_read(0, want_types=False)
         total = float(big.sum(dtype=np.float64))
         assert abs(int(cnt16[1]) - int(nsel[1])) <= 0.001 * nsel[1]
@@ -771,7 +771,7 @@ def test_explicit_binned_request_fails_loudly_when_unsupported(S):
         S.deposit_host(1, f["pos"])
     assert e.value.code == slicer_amd.api.ERR_UNSUPPORTED
     out = run_gpu(S, [f], 64, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_AUTO)
-    assert S.algo_mask() == 1 << slicer_amd.ALGO_DIRECT
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_DIRECT
     for p in range(2):
         ref_tot, _, nsel = run_oracle([f], 64, 0.25, lds[p], ld2s[p], ngp=True)
         assert np.array_equal(out[p][2], nsel) and np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32))
@@ -822,3 +822,57 @@ def test_reduce_meta_stand_ins_and_scale_check(S, accum):
     with pytest.raises(slicer_amd.SlicerError) as e:
         S.plane_read(0)
     assert e.value.code == 1
+
+
+def test_fast_projection_error_budget(S):
+    """k_project_bin_fast trusts its fp64 projection only where a 2^-41 window decides the rounding: the refined
+    reciprocal and reciprocal square root it is built on must be good to well below that (ops 8 / 9 of
+    slicer_debug_math); the raw hardware estimates (ops 6 / 7) are reported for the record."""
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.uniform(0.5, 40.0, 1 << 20), 2.0 ** rng.uniform(-60, 60, 1 << 20)])
+    exact_rs, exact_rc = 1.0 / np.sqrt(a.astype(np.longdouble)), 1.0 / a.astype(np.longdouble)
+    err = {}
+    for op, ref in ((6, exact_rs), (7, exact_rc), (8, exact_rs), (9, exact_rc)):
+        got = S.debug_math(op, a).astype(np.longdouble)
+        err[op] = float(np.max(np.abs(got - ref) / ref))
+    print("relative error: v_rsq_f64 %.2e, v_rcp_f64 %.2e, refined %.2e / %.2e" % (err[6], err[7], err[8], err[9]))
+    assert err[8] < 2.0 ** -48 and err[9] < 2.0 ** -48
+
+
+def test_box_quotient_sweep(S):
+    """the f32 form of r / box used by the fast project+bin kernel is licensed per box size by an
+    exhaustive device sweep over all 2^31 non-negative binary32 values against (float)((double)r / box)."""
+    for box in (1000.0, 500000.0, 250.0, 64.0, 3.3e6, 1000.5):   # binary32 values
+        n, ex = S.debug_box_quotient(box)
+        assert n == 0, (box, n, ex)
+    n, ex = S.debug_box_quotient(0.1)    # not a binary32 value: double rounding is not innocuous, the sweep says so
+    assert n > 0
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_fast_and_general_project_bin_kernels_agree(S, general, monkeypatch):
+    """Both K1 variants against the oracle on the same cases: records bit-identical => NGP maps bit-exact; the variant
+    that ran is read back from the algo mask (bit 4 fast, bit 5 general)."""
+    if general:
+        monkeypatch.setenv("SLICER_K1_GENERAL", "1")
+    f32c = tuple(float(np.float32(c)) for c in (0.3, 0.6, 0.1))
+    # (randomisation, does it qualify for the fast kernel): f32 centres do; double-precision centres and the exact 0 of
+    # -DUSE_FIXED_PLC_VERTEX are left to the general kernel
+    cases = [(dict(RND, center=f32c), True), (dict(RND, center=(0.3, 0.6, 0.1)), False),
+             (dict(sgn=(1, -1, 1), face=5, center=f32c, rcase=0.0), True),
+             (dict(sgn=(1, 1, -1), face=6, center=f32c, rcase=1.0), True),
+             (dict(sgn=(-1, -1, 1), face=2, center=(0.0, 0.0, 0.5), rcase=2.0), False)]
+    vals = np.array([0.0, -0.0, BOX, 1e-30, 0.5 * BOX, 0.999999 * BOX, np.nextafter(np.float32(BOX), np.float32(0))],
+                    np.float32)
+    edge = np.array(list(itertools.product(vals, repeat=3)), np.float32)
+    pos = np.concatenate([synth.positions(0, 300000, BOX), edge])
+    f = dict(npart=[0, len(pos), 0, 0, 0, 0], massarr=[0, 0.0123, 0, 0, 0, 0], boxsize=BOX, pos=pos)
+    for rnd, qualifies in cases:
+        lo = rnd["rcase"]
+        lds, ld2s = [lo, lo + 0.25, lo + 0.5, lo + 0.75], [lo + 0.25, lo + 0.5, lo + 0.75, lo + 1.0]
+        out = run_gpu(S, [f], 512, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+        assert S.algo_mask() >> 4 == (2 if (general or not qualifies) else 1)
+        for p in range(4):
+            ref_tot, _, nsel = run_oracle([f], 512, 0.25, lds[p], ld2s[p], ngp=True, rnd=rnd)
+            assert np.array_equal(out[p][2], nsel)
+            assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), (rnd, p)
