@@ -126,12 +126,24 @@ __device__ __forceinline__ void transform(float rx, float ry, float rz, const Pa
 // halves the dependent-FMA depth; the series value is p = pe(w) + z*po(w).
 // r * w + c with the coefficient in a scalar register pair: the coefficients of both series would otherwise sit in 52
 // VGPRs (and cost a v_mov_b64 per term, v_fmac_f64 being destructive); s_mov of a literal is off the VALU port.
-__device__ __forceinline__ double fma_sc(double r, double w, double c)
+// The literal is materialised by two s_mov inside volatile asm, i.e. next to its use: left to the compiler, the 18
+// coefficients of the two series are hoisted out of the particle loop, where they pin 36 SGPRs and push the loop's own
+// uniform operands into spill lanes (a v_readlane per use: VALU slots, the kernel's bound).  s_mov runs on the scalar
+// port.
+constexpr unsigned long long dbits(double d) { return __builtin_bit_cast(unsigned long long, d); }
+
+template <unsigned long long C>
+__device__ __forceinline__ double fma_sc(double r, double w)
 {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)(C & 0xFFFFFFFFull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(C >> 32)));
+    const double c = __hiloint2double((int)hi, (int)lo);
     double o;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(r), "v"(w), "s"(c));
     return o;
 }
+#define FMA_SC(r, w, c) fma_sc<dbits(c)>(r, w)
 
 // N = 15 terms serve |x| <= 0.3125; N = 9 terms serve |x| <= 0.155 (fields of view up to ~17 deg) with the same
 // truncation bound (A10 z^10 and z^10 / 21 are below 0.03 ulp there) and six fewer dependent fp64 FMAs per series.
@@ -145,23 +157,23 @@ __device__ __forceinline__ double asin_small(double x)
     // A1..AN split: even-index chain (A1, A3, ..., AN) and odd-index chain (A2, A4, ..., A(N-1))
     double pe, po;
     if (N == 15) {
-        pe = fma_sc(0x1.31683bdef7bdfp-8, w, 0x1.782dda12f684cp-8);  // A15, A13
-        po = fma_sc(0x1.51ba308d3dcb1p-8, w, 0x1.a6863d70a3d71p-8);  // A14, A12
-        pe = fma_sc(pe, w, 0x1.df3bd37a6f4dfp-8);     // A11
-        po = fma_sc(po, w, 0x1.12ef3cf3cf3cfp-7);     // A10
-        pe = fma_sc(pe, w, 0x1.3fde50d79435ep-7);     // A9
-        po = fma_sc(po, w, 0x1.7a87878787878p-7);     // A8
-        pe = fma_sc(pe, w, 0x1.c99999999999ap-7);     // A7
-        po = fma_sc(po, w, 0x1.1c4ec4ec4ec4fp-6);     // A6
+        pe = FMA_SC(0x1.31683bdef7bdfp-8, w, 0x1.782dda12f684cp-8);  // A15, A13
+        po = FMA_SC(0x1.51ba308d3dcb1p-8, w, 0x1.a6863d70a3d71p-8);  // A14, A12
+        pe = FMA_SC(pe, w, 0x1.df3bd37a6f4dfp-8);     // A11
+        po = FMA_SC(po, w, 0x1.12ef3cf3cf3cfp-7);     // A10
+        pe = FMA_SC(pe, w, 0x1.3fde50d79435ep-7);     // A9
+        po = FMA_SC(po, w, 0x1.7a87878787878p-7);     // A8
+        pe = FMA_SC(pe, w, 0x1.c99999999999ap-7);     // A7
+        po = FMA_SC(po, w, 0x1.1c4ec4ec4ec4fp-6);     // A6
     } else {
-        pe = fma_sc(0x1.3fde50d79435ep-7, w, 0x1.c99999999999ap-7);  // A9, A7
-        po = fma_sc(0x1.7a87878787878p-7, w, 0x1.1c4ec4ec4ec4fp-6);  // A8, A6
+        pe = FMA_SC(0x1.3fde50d79435ep-7, w, 0x1.c99999999999ap-7);  // A9, A7
+        po = FMA_SC(0x1.7a87878787878p-7, w, 0x1.1c4ec4ec4ec4fp-6);  // A8, A6
     }
-    pe = fma_sc(pe, w, 0x1.6e8ba2e8ba2e9p-6);         // A5
-    po = fma_sc(po, w, 0x1.f1c71c71c71c7p-6);         // A4
-    pe = fma_sc(pe, w, 0x1.6db6db6db6db7p-5);         // A3
-    po = fma_sc(po, w, 0x1.3333333333333p-4);         // A2
-    pe = fma_sc(pe, w, 0x1.5555555555555p-3);         // A1
+    pe = FMA_SC(pe, w, 0x1.6e8ba2e8ba2e9p-6);         // A5
+    po = FMA_SC(po, w, 0x1.f1c71c71c71c7p-6);         // A4
+    pe = FMA_SC(pe, w, 0x1.6db6db6db6db7p-5);         // A3
+    po = FMA_SC(po, w, 0x1.3333333333333p-4);         // A2
+    pe = FMA_SC(pe, w, 0x1.5555555555555p-3);         // A1
     const double p = fma(po, z, pe);                  // A1 + A2 z + A3 z^2 + ...
     return fma(x * z, p, x);
 }
@@ -173,23 +185,23 @@ __device__ __forceinline__ double atan_small(double t)
     const double z = t * t, w = z * z;
     double pe, po;
     if (N == 15) {
-        pe = fma_sc(-0x1.0842108421084p-5, w, -0x1.2f684bda12f68p-5);  // -1/31, -1/27
-        po = fma_sc(0x1.1a7b9611a7b96p-5, w, 0x1.47ae147ae147bp-5);    // +1/29, +1/25
-        pe = fma_sc(pe, w, -0x1.642c8590b2164p-5);    // -1/23
-        po = fma_sc(po, w, 0x1.8618618618618p-5);     // +1/21
-        pe = fma_sc(pe, w, -0x1.af286bca1af28p-5);    // -1/19
-        po = fma_sc(po, w, 0x1.e1e1e1e1e1e1ep-5);     // +1/17
-        pe = fma_sc(pe, w, -0x1.1111111111111p-4);    // -1/15
-        po = fma_sc(po, w, 0x1.3b13b13b13b14p-4);     // +1/13
+        pe = FMA_SC(-0x1.0842108421084p-5, w, -0x1.2f684bda12f68p-5);  // -1/31, -1/27
+        po = FMA_SC(0x1.1a7b9611a7b96p-5, w, 0x1.47ae147ae147bp-5);    // +1/29, +1/25
+        pe = FMA_SC(pe, w, -0x1.642c8590b2164p-5);    // -1/23
+        po = FMA_SC(po, w, 0x1.8618618618618p-5);     // +1/21
+        pe = FMA_SC(pe, w, -0x1.af286bca1af28p-5);    // -1/19
+        po = FMA_SC(po, w, 0x1.e1e1e1e1e1e1ep-5);     // +1/17
+        pe = FMA_SC(pe, w, -0x1.1111111111111p-4);    // -1/15
+        po = FMA_SC(po, w, 0x1.3b13b13b13b14p-4);     // +1/13
     } else {
-        pe = fma_sc(-0x1.af286bca1af28p-5, w, -0x1.1111111111111p-4);  // -1/19, -1/15
-        po = fma_sc(0x1.e1e1e1e1e1e1ep-5, w, 0x1.3b13b13b13b14p-4);    // +1/17, +1/13
+        pe = FMA_SC(-0x1.af286bca1af28p-5, w, -0x1.1111111111111p-4);  // -1/19, -1/15
+        po = FMA_SC(0x1.e1e1e1e1e1e1ep-5, w, 0x1.3b13b13b13b14p-4);    // +1/17, +1/13
     }
-    pe = fma_sc(pe, w, -0x1.745d1745d1746p-4);        // -1/11
-    po = fma_sc(po, w, 0x1.c71c71c71c71cp-4);         // +1/9
-    pe = fma_sc(pe, w, -0x1.2492492492492p-3);        // -1/7
-    po = fma_sc(po, w, 0x1.999999999999ap-3);         // +1/5
-    pe = fma_sc(pe, w, -0x1.5555555555555p-2);        // -1/3
+    pe = FMA_SC(pe, w, -0x1.745d1745d1746p-4);        // -1/11
+    po = FMA_SC(po, w, 0x1.c71c71c71c71cp-4);         // +1/9
+    pe = FMA_SC(pe, w, -0x1.2492492492492p-3);        // -1/7
+    po = FMA_SC(po, w, 0x1.999999999999ap-3);         // +1/5
+    pe = FMA_SC(pe, w, -0x1.5555555555555p-2);        // -1/3
     const double p = fma(po, z, pe);
     return fma(t * z, p, t);
 }
