@@ -34,11 +34,14 @@ constexpr int kScanBins = 32;               // bins per workgroup of k_scan_bloc
 constexpr int kScanSegs = 1024 / kScanBins;  // segments of the K1-workgroup axis
 
 __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__restrict__ hist16,
-                                                      unsigned *__restrict__ prefix, unsigned *__restrict__ total,
-                                                      int nblocks, int nbins)
+                                                      unsigned *__restrict__ prefix, unsigned *__restrict__ lex,
+                                                      unsigned *__restrict__ gsum, int nblocks, int nbins)
 {
     // 32 bins (a half-wave reads 64 contiguous bytes of a histogram row) x 32 segments of the workgroup axis:
-    // 256 workgroups for 8192 bins, 16 rows per lane at 512 K1 workgroups
+    // 256 workgroups for 8192 bins, 16 rows per lane at 512 K1 workgroups.
+    // Besides the per-(workgroup, bin) write cursors it leaves, for the bins of its group, the exclusive prefix of the
+    // bin totals inside the group (lex) and the group's sum (gsum): the sort kernel turns those into bin bases itself
+    // (a 256-entry scan per workgroup), which saves the single-workgroup scan launch that used to sit in between.
     __shared__ unsigned s_seg[kScanSegs][kScanBins];
     const int bl = threadIdx.x % kScanBins, seg = threadIdx.x / kScanBins;
     const int bin = blockIdx.x * kScanBins + bl;
@@ -60,69 +63,20 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
             prefix[(size_t)b * nbins + bin] = run;
             run += v;
         }
-        if (seg == kScanSegs - 1)
-            total[bin] = run;
     }
-}
-
-// K2b: exclusive scan over bins (single workgroup), base[nbins] = total record count
-// With count_planes set it also adds every plane's record count (= its selected entries on the TSC path) to nsel.
-__global__ __launch_bounds__(1024) void k_scan_bins(const unsigned *__restrict__ total, unsigned *__restrict__ base,
-                                                    int nbins, int count_planes, int bins_per_plane, Targets T)
-{
-    // a lane owns kScanPer consecutive bins of each 1024 * kScanPer-bin slab; its loads are issued together
-    // (a loop of dependent load -> add round trips made this single-workgroup kernel latency-bound)
-    constexpr int kScanPer = 8;
-    __shared__ unsigned s_wave[1024 / 64], s_pre[kMaxPlanes + 1];
-    __shared__ unsigned s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0)
-        s_carry = 0;
-    __syncthreads();
-    for (int slab = 0; slab < nbins; slab += 1024 * kScanPer) {
-        const int lo = slab + tid * kScanPer;
-        unsigned v[kScanPer];
+    if (seg == kScanSegs - 1) {  // lanes 992..1023: one half-wave holds the totals of the group's 32 bins
+        const unsigned tot = bin < nbins ? run : 0u;
+        unsigned x = tot;
 #pragma unroll
-        for (int j = 0; j < kScanPer; j++)
-            v[j] = lo + j < nbins ? total[lo + j] : 0u;
-        unsigned sum = 0;
-#pragma unroll
-        for (int j = 0; j < kScanPer; j++)
-            sum += v[j];
-        unsigned x = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned y = (unsigned)__shfl_up((int)x, d);
-            if ((int)(tid & 63) >= d)
+        for (int d = 1; d < kScanBins; d <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, d, kScanBins);
+            if (bl >= d)
                 x += y;
         }
-        if ((tid & 63) == 63)
-            s_wave[tid >> 6] = x;
-        __syncthreads();
-        unsigned run = s_carry + x - sum;
-        for (int k = 0; k < (tid >> 6); k++)
-            run += s_wave[k];
-#pragma unroll
-        for (int j = 0; j < kScanPer; j++) {
-            const int i = lo + j;
-            if (i < nbins) {
-                base[i] = run;
-                if (count_planes && i % bins_per_plane == 0)
-                    s_pre[i / bins_per_plane] = run;  // records before the first bin of a plane
-            }
-            run += v[j];
-        }
-        __syncthreads();
-        if (tid == 1023)
-            s_carry = run;
-        __syncthreads();
-    }
-    if (tid == 0)
-        base[nbins] = s_carry;
-    if (tid < count_planes) {
-        const unsigned c = (tid + 1 < count_planes ? s_pre[tid + 1] : s_carry) - s_pre[tid];
-        if (c)
-            atomicAdd(T.nsel[tid], (unsigned long long)c);
+        if (bin < nbins)
+            lex[bin] = x - tot;
+        if (bl == kScanBins - 1)
+            gsum[blockIdx.x] = x;
     }
 }
 
@@ -169,29 +123,18 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s
     return off + x - v;
 }
 
-// The tile of a record is recomputed from (xs, ys) -- the same grid_index / clamp / tile arithmetic K1 used for its
-// histogram -- instead of being stored next to it: 2 bytes per record less to write and to read back, and this kernel
-// is bound by memory, not by instructions.
-__device__ __forceinline__ unsigned record_tile(float2 xy, int band, const GridParams &g, const BinGeom &G)
-{
-    int gx = grid_index_rt(xy.x, g), gy = grid_index_rt(xy.y, g);
-    // TSC records of the border ring were binned with the clamped cell; NGP records are always on the grid
-    gx = gx < 0 ? 0 : (gx >= g.nn ? g.nn - 1 : gx);
-    gy = gy < 0 ? 0 : (gy >= g.nn ? g.nn - 1 : gy);
-    const unsigned ty = (unsigned)(gy >> G.th_log2), tx = (unsigned)(gx >> G.tw_log2);
-    return (ty - (unsigned)band * (unsigned)G.rows_per_unit) * (unsigned)G.ntx + tx;
-}
-
 template <bool HAS_MASS>
 __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(const float2 *__restrict__ cxy,
-                                                            GridParams grid,
+                                                            const unsigned short *__restrict__ cbin,
                                                             const float *__restrict__ cm,
                                                             const unsigned *__restrict__ hist16w,
                                                             const unsigned *__restrict__ prefix,
-                                                            const unsigned *__restrict__ base,
+                                                            const unsigned *__restrict__ lex,
+                                                            const unsigned *__restrict__ gsum,
+                                                            unsigned *__restrict__ base,
                                                             const unsigned *__restrict__ bcount, int nblocks,
                                                             BinGeom G, float2 *__restrict__ sxy,
-                                                            float *__restrict__ sm)
+                                                            float *__restrict__ sm, int count_planes, Targets T)
 {
     extern __shared__ unsigned smem_sc[];
     const int tpp = G.tiles_per_unit;
@@ -203,8 +146,45 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
     unsigned short *sorted_tile = reinterpret_cast<unsigned short *>(sorted_xy + kSortStage);
     float *sorted_m = reinterpret_cast<float *>(sorted_tile + kSortStage);  // HAS_MASS only
     __shared__ unsigned s_wave[kSortBlock / 64];
+    __shared__ unsigned s_gp[kMaxBins / kScanBins + 1];  // exclusive prefix of the scan kernel's group sums
 
     const int tid = threadIdx.x;
+    // bin bases: base[bin] = s_gp[bin / 32] + lex[bin].  Every workgroup scans the (<= 1024) group sums for itself;
+    // workgroup 0 also writes base[] out for the tile kernel and adds every plane's record count (= its selected
+    // entries on the TSC path) to the counters.
+    {
+        const int ngroups = (G.nbins + kScanBins - 1) / kScanBins;
+        constexpr int kPerLane = (kMaxBins / kScanBins + kSortBlock - 1) / kSortBlock;  // 2 at 512 threads
+        unsigned v[kPerLane], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPerLane; j++) {
+            const int g = tid * kPerLane + j;
+            v[j] = g < ngroups ? gsum[g] : 0u;
+            sum += v[j];
+        }
+        unsigned e = block_exclusive_scan(sum, s_wave);
+#pragma unroll
+        for (int j = 0; j < kPerLane; j++) {
+            const int g = tid * kPerLane + j;
+            if (g < ngroups)
+                s_gp[g] = e;
+            e += v[j];
+        }
+        if (tid == kSortBlock - 1)
+            s_gp[ngroups] = e;  // all records
+        lds_barrier();
+        if (blockIdx.x == 0) {
+            for (int i = tid; i <= G.nbins; i += kSortBlock)
+                base[i] = i < G.nbins ? s_gp[i / kScanBins] + lex[i] : s_gp[ngroups];
+            if (tid < count_planes) {
+                const int bpp = G.units_per_plane * G.tiles_per_unit;  // bins per plane
+                auto at = [&](int i) { return i < G.nbins ? s_gp[i / kScanBins] + lex[i] : s_gp[ngroups]; };
+                const unsigned c = at((tid + 1) * bpp) - at(tid * bpp);
+                if (c)
+                    atomicAdd(T.nsel[tid], (unsigned long long)c);
+            }
+        }
+    }
     // Persistent workgroups: each takes the (unit, K1 workgroup) items b, b + gridDim.x, ...  item -> (unit, K1
     // workgroup) keeps an XCD's items on a contiguous range of K1 workgroups (gridDim.x is a multiple of 8, so
     // item & 7 is this workgroup's XCD): runs of one tile written by neighbouring K1 workgroups then meet in the
@@ -225,11 +205,11 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
             continue;
         lds_barrier();  // the previous item's tables are no longer read
         const unsigned *row = prefix + (size_t)lb * G.nbins + (size_t)plane * tpp;
-        const unsigned *brow = base + (size_t)plane * tpp;
+        const unsigned *lrow = lex + (size_t)plane * tpp;
+        const unsigned bin0 = (unsigned)plane * (unsigned)tpp;
         for (int i = tid; i < tpp; i += kSortBlock)
-            cur[i] = brow[i] + row[i];
+            cur[i] = s_gp[(bin0 + (unsigned)i) / kScanBins] + lrow[i] + row[i];
         const uint64_t r0 = ((uint64_t)plane * nblocks + lb) * (uint64_t)G.region;
-        const int band = plane % G.units_per_plane;  // `plane` is the unit index here
 
         // A region that fits one sub-batch (the usual case) needs no counting pass: its per-tile counts are this K1
         // workgroup's histogram row, already in the packed layout of cnt (needs the unit's first bin word-aligned).
@@ -248,8 +228,8 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
             for (int k = 0; k < R; k++) {
                 const unsigned i = (unsigned)k * kSortBlock + tid;
                 if (i < nsub) {
+                    tile[k] = cbin[r0 + s0 + i];
                     xy[k] = cxy[r0 + s0 + i];
-                    tile[k] = record_tile(xy[k], band, grid, G);
                     if (HAS_MASS)
                         m[k] = cm[r0 + s0 + i];
                     if (!single)
@@ -395,20 +375,30 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     const int tid = threadIdx.x;
     const int nn = P.nn;
     constexpr int U = 4;  // records in flight per lane
-    for (int c = 0; c < L.n; c++) {
-        // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts)
+    // The waves of the workgroup are dealt to the pending chunks round-robin (wave w -> chunk w % n, as member w / n of
+    // the waves that share the chunk), so that the runs of all chunks stream in at once and a lane walks ~10 records of
+    // one run, instead of the whole workgroup crossing the (short) runs one after the other with most lanes idle.
+    constexpr int kWavesT = kTileBlock / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    {
+        const int c = wave % L.n, k = wave / L.n;
+        const int m = (kWavesT - c + L.n - 1) / L.n;  // waves on chunk c
+        // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts); this wave's slice of it
         const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
-        const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
-        const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+        const unsigned pstart = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
+        const unsigned pend = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+        const unsigned plen = pend - pstart;
+        const unsigned start = pstart + (unsigned)(((unsigned long long)plen * (unsigned)k) / (unsigned)m);
+        const unsigned end = pstart + (unsigned)(((unsigned long long)plen * (unsigned)(k + 1)) / (unsigned)m);
         const float2 *__restrict__ sxy = L.sxy[c];
         const float *__restrict__ sm = L.sm[c];
         const float mconst = L.mconst[c], smc = L.sm_const[c];
-        for (unsigned i0 = start; i0 < end; i0 += U * kTileBlock) {
+        for (unsigned i0 = start; i0 < end; i0 += U * 64) {
             float2 r[U];
             float mr[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const unsigned i = i0 + u * kTileBlock + tid;
+                const unsigned i = i0 + u * 64 + lane;
                 if (i < end) {
                     r[u] = sxy[i];
                     if (HAS_MASS)
@@ -417,7 +407,7 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const unsigned i = i0 + u * kTileBlock + tid;
+                const unsigned i = i0 + u * 64 + lane;
                 if (i >= end)
                     continue;
                 const float xs = r[u].x, ys = r[u].y;
@@ -526,10 +516,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s)
 {
-    k_scan_blocks<<<(G.nbins + kScanBins - 1) / kScanBins, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
-                                                         nblocks, G.nbins);
-    k_scan_bins<<<1, 1024, 0, s>>>(W.total, W.base, G.nbins, cfg.mas == kTSC ? n_planes : 0,
-                                   G.units_per_plane * G.tiles_per_unit, T);
+    (void)cfg, (void)n_planes, (void)T;
+    const int ngroups = (G.nbins + kScanBins - 1) / kScanBins;
+    k_scan_blocks<<<ngroups, 1024, 0, s>>>(reinterpret_cast<const unsigned short *>(W.hist16), W.hist, W.total,
+                                           W.total + kMaxBins, nblocks, G.nbins);
     return hipGetLastError();
 }
 
@@ -539,33 +529,29 @@ size_t scatter_lds_bytes(const BinGeom &G, bool has_mass)
     return 4 * (tw + 2 * tpp + (tw & 1)) + (size_t)kSortStage * (8 + 2 + (has_mass ? 4 : 0));
 }
 
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const PassParams &P, int mas,
-                              const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, int max_workgroups, const BinGeom &G,
+                              const BinWorkspace &W, const Targets &T, hipStream_t s)
 {
-    GridParams grid;
-    grid.nn = P.nn;
-    grid.pow2 = P.pow2;
-    grid.ngp = mas == kNGP;
-    grid.nn_f = P.nn_f;
-    grid.dl = P.dl;
+    const bool has_mass = cfg.has_mass;
     const size_t lds = scatter_lds_bytes(G, has_mass);
     const int items = G.n_units * 8 * ((nblocks + 7) / 8);
     const int nwg = std::min(items, std::max(8, max_workgroups / 8 * 8));
+    const int count_planes = cfg.mas == kTSC ? n_planes : 0;
     hipError_t e;
     if (has_mass) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<true><<<nwg, kSortBlock, lds, s>>>(W.cxy, grid, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                          W.sm);
+        k_bin_scatter<true><<<nwg, kSortBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist16, W.hist, W.total, W.total + kMaxBins,
+                                                          W.base, W.bcount, nblocks, G, W.sxy, W.sm, count_planes, T);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        k_bin_scatter<false><<<nwg, kSortBlock, lds, s>>>(W.cxy, grid, W.cm, W.hist16, W.hist, W.base, W.bcount, nblocks, G, W.sxy,
-                                                           W.sm);
+        k_bin_scatter<false><<<nwg, kSortBlock, lds, s>>>(W.cxy, W.cbin, W.cm, W.hist16, W.hist, W.total, W.total + kMaxBins,
+                                                           W.base, W.bcount, nblocks, G, W.sxy, W.sm, count_planes, T);
     }
     return hipGetLastError();
 }

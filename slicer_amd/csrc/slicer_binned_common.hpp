@@ -43,18 +43,4 @@ __device__ __forceinline__ void cell_to_tile(int gx, int gy, int plane, const Bi
     tile_in_unit = trow * (unsigned)G.ntx + tx;
 }
 
-// The grid parameters the sort kernel needs to recompute a record's tile from (xs, ys) (K1 no longer stores it).
-struct GridParams {
-    int nn, pow2, ngp;
-    float nn_f;
-    double dl;
-};
-
-__device__ __forceinline__ int grid_index_rt(float v, const GridParams &g)
-{
-    if (g.pow2)
-        return (int)floorf(v * g.nn_f);   // utilities.cpp:69-70, exact scaling (see grid_index<true>)
-    return (int)floor((double)v / g.dl);
-}
-
 }  // namespace slicer

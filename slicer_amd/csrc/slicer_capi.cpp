@@ -79,7 +79,7 @@ struct slicer_handle_s {
     uint64_t stage_cap = 0;  // particles
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
-    DevBuf w_cxy, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
     // box sizes whose f32 quotient r/box passed (true) or failed (false) the exhaustive device sweep
     // (launch_check_box_quotient): k_project_bin_fast is only used for the former
     std::vector<std::pair<double, bool>> box_verdicts;
@@ -404,7 +404,6 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
 }
 
 constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
-constexpr int kMaxBins = 32768;   // all (unit, tile) bins of a pass: K1's packed u16 histogram is <= 64 KiB of LDS
 constexpr int kUnitBins = 8192;   // up to this many bins the units are whole planes
 
 // Tile geometry of the binned path.  Tiles are powers of two so that pixel -> tile is a shift.  4-byte
@@ -579,15 +578,17 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, c
     const uint64_t region = (uint64_t)G.n_units * nb * G.region;  // compact records: [unit][workgroup][region]
     const uint64_t nrec = n * (uint64_t)(G.region / G.batch);     // most records this chunk can emit
     int rc;
-    if ((rc = ensure(h, h->w_cxy, region * 8)) ||
+    if ((rc = ensure(h, h->w_cxy, region * 8)) || (rc = ensure(h, h->w_cbin, region * 2)) ||
         (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
-        (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) || (rc = ensure(h, h->w_total, kMaxBins * 4)) ||
+        (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) ||
+        (rc = ensure(h, h->w_total, (kMaxBins + kMaxBins / 32 + 1) * 4)) ||
         (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, h->w_sxy[slot], nrec * 8)) ||
         (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
     if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], nrec * 4))))
         return rc;
     W.cxy = (float2 *)h->w_cxy.p;
+    W.cbin = (unsigned short *)h->w_cbin.p;
     W.cm = (float *)h->w_cm.p;
     W.sxy = (float2 *)h->w_sxy[slot].p;
     W.sm = (float *)h->w_sm[slot].p;
@@ -717,7 +718,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     }
     {
         ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(has_mass, nblocks, scatter_workgroups(h), P, cfg.mas, G, W, h->stream));
+        HIPCHK(h, launch_bin_scatter(cfg, nblocks, P.n_planes, scatter_workgroups(h), G, W, T, h->stream));
     }
     if (slot == 0) {
         h->pend_key = key;
@@ -861,7 +862,7 @@ int slicer_destroy(slicer_handle h)
     }
     if (h->d_sweep)
         (void)hipFree(h->d_sweep);
-    for (DevBuf *b : {&h->w_cxy, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
+    for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
                       &h->w_tcounts, &h->w_tbase, &h->w_urand})
         release(*b);
     for (int i = 0; i < kMaxPending; i++) {

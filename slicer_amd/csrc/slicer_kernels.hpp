@@ -81,16 +81,18 @@ struct BinGeom {
                            // batch * (2 nrepperp + 1)^2 (lateral replication, densitymaps.cpp:377-399), <= 65535
 };
 constexpr int kMaxUnits = 32;
+constexpr int kMaxBins = 32768;  // all (unit, tile) bins of a pass: K1's packed u16 histogram is <= 64 KiB of LDS
 
 struct BinWorkspace {
     float2 *cxy;       // [n_units][nblocks][region] compact (xs, ys) of (unit, K1 workgroup), bcount[unit][b] valid
+    unsigned short *cbin;  // same shape: tile-in-unit of each compact record (K3 sorts by it)
     float *cm;         // same shape: per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
     float *sm;         // [max_chunk] or nullptr
     unsigned *hist16;  // [nblocks][ceil(nbins/2)] per-workgroup histogram, two u16 counters per word
     unsigned *hist;    // [nblocks][nbins] exclusive prefix over workgroups (write cursors)
-    unsigned *total;   // [nbins]
-    unsigned *base;    // [nbins + 1] start of every bin's run in sxy
+    unsigned *total;   // [nbins] exclusive prefix of the bin totals inside each group of kScanBins bins | [ngroups] group sums
+    unsigned *base;    // [nbins + 1] start of every bin's run in sxy (written by the sort kernel for the tile kernel)
     unsigned *bcount;  // [n_units][nblocks]
 };
 
@@ -101,6 +103,7 @@ struct K1Args {
     const float *mass;         // per-particle masses or nullptr
     uint64_t n;
     float2 *cxy;
+    unsigned short *cbin;
     float *cm;
     unsigned *hist16;
     unsigned *bcount;
@@ -138,8 +141,8 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_po
                               const Targets &T, hipStream_t s);
 hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, const BinGeom &G, const BinWorkspace &W,
                            const Targets &T, hipStream_t s);
-hipError_t launch_bin_scatter(bool has_mass, int nblocks, int max_workgroups, const PassParams &P, int mas,
-                              const BinGeom &G, const BinWorkspace &W, hipStream_t s);
+hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, int max_workgroups, const BinGeom &G,
+                              const BinWorkspace &W, const Targets &T, hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
 constexpr int kMaxPending = 8;

@@ -168,6 +168,7 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
         const unsigned o = atomicAdd(&s_out[unit], 1u);
         const unsigned idx = unit * unit_stride + o;
         out_wg[idx] = make_float2(xs, ys);
+        A.cbin[(size_t)blockIdx.x * (size_t)A.batch + idx] = (unsigned short)(trow * (unsigned)A.ntx + tx);
         if (A.mass != nullptr)
             A.cm[(size_t)blockIdx.x * (size_t)A.batch + idx] = A.mass[b0 + idx_in_batch];
         atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
 template <int MAS, bool POW2, bool HAS_MASS, int SERIES, bool REP>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin_general(
     const float *__restrict__ pos, const float *__restrict__ mass, uint64_t n, int vec, PassParams P, BinGeom G,
-    float2 *__restrict__ cxy, float *__restrict__ cm, unsigned *__restrict__ hist16, unsigned *__restrict__ bcount,
-    Targets T)
+    float2 *__restrict__ cxy, unsigned short *__restrict__ cbin, float *__restrict__ cm, unsigned *__restrict__ hist16,
+    unsigned *__restrict__ bcount, Targets T)
 {
     extern __shared__ unsigned smem[];
     unsigned *s_hist = smem;
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 const unsigned o = atomicAdd(&s_out[unit], 1u);
                 const uint64_t dst = ((uint64_t)unit * gridDim.x + blockIdx.x) * (uint64_t)G.region + o;
                 cxy[dst] = make_float2(xs, ys);
+                cbin[dst] = (unsigned short)tile_in_unit;
                 if (HAS_MASS)
                     cm[dst] = m;
                 atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
@@ -649,12 +651,12 @@ static hipError_t launch_k1_general(bool vec, const float *pos, const float *mas
         auto kern = k_project_bin_general<MAS, POW2, HAS_MASS, SERIES, true>;
         if ((e = set_lds(kern, lds)) != hipSuccess)
             return e;
-        kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, vec ? 1 : 0, P, G, W.cxy, W.cm, W.hist16, W.bcount, T);
+        kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, vec ? 1 : 0, P, G, W.cxy, W.cbin, W.cm, W.hist16, W.bcount, T);
     } else {
         auto kern = k_project_bin_general<MAS, POW2, HAS_MASS, SERIES, false>;
         if ((e = set_lds(kern, lds)) != hipSuccess)
             return e;
-        kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, vec ? 1 : 0, P, G, W.cxy, W.cm, W.hist16, W.bcount, T);
+        kern<<<nb, kK1Block, lds, s>>>(pos, mass, n, vec ? 1 : 0, P, G, W.cxy, W.cbin, W.cm, W.hist16, W.bcount, T);
     }
     return hipGetLastError();
 }
@@ -674,6 +676,7 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_po
         A.vec = vec ? 1 : 0;
         A.ngp = cfg.mas == kNGP;
         A.cxy = W.cxy;
+        A.cbin = W.cbin;
         A.cm = W.cm;
         A.hist16 = W.hist16;
         A.bcount = W.bcount;
