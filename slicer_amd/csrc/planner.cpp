@@ -17,55 +17,44 @@ using std::endl;
 using std::string;
 using std::vector;
 
-// ---------------------------------------------------------------- w0waCDM.cpp:8-84
-w0waCDM::w0waCDM(double H0_, double OmegaM_, double OmegaLambda_, double w0_, double wa_)
-    : H0(H0_), OmegaM(OmegaM_), OmegaLambda(OmegaLambda_), w0(w0_), wa(wa_)
+// ---------------------------------------------------------------- distance table
+// What the reference's start-up needs from its cosmology class (w0waCDM.{h,cpp}, used at slicer-v2.cpp:79-86) is one
+// table: the transverse comoving distance at an increasing grid of redshifts starting at 0.  Numeric contract kept,
+// because the plane edges derive from it: each grid interval is integrated with the trapezoid rule in steps of 1/100 of
+// the interval, the abscissa advancing by repeated addition until it reaches the interval's end -- so rounding lets some
+// intervals take a 101st trapezoid (a +0.06 % bias of the reference that a "better" quadrature would not reproduce).
+double expansionRate(const Cosmology &c, double z)
 {
-    if (H0 <= 0 || OmegaM < 0 || OmegaLambda < 0)
-        throw std::invalid_argument("Invalid cosmological parameters: H0 must be positive, and density parameters "
-                                    "cannot be negative.");
+    const double a1 = 1.0 + z;
+    const double dark = c.omegaLambda * pow(a1, 3.0 * (1.0 + c.w0 + c.wa)) * exp(-3.0 * c.wa * z / a1);
+    const double curvature = (1.0 - c.omegaM - c.omegaLambda) * pow(a1, 2);
+    return c.h0 * sqrt(dark + c.omegaM * pow(a1, 3) + curvature);
 }
 
-double w0waCDM::Hz(double z) const
+std::vector<double> transverseDistanceTable(const Cosmology &c, const std::vector<double> &zgrid)
 {
-    double rhoLambda = OmegaLambda * pow(1 + z, 3 * (1 + w0 + wa)) * exp(-3 * wa * z / (1 + z));
-    double rhoM = OmegaM * pow(1 + z, 3);
-    double rhoTot = rhoLambda + rhoM + (1 - OmegaM - OmegaLambda) * pow(1 + z, 2);
-    return H0 * sqrt(rhoTot);
-}
-
-double w0waCDM::comovingDistance(double z) const
-{
-    // NB (reference behaviour kept): a cache hit returns the stored value WITHOUT the c factor (w0waCDM.cpp:33-36);
-    // the driver only ever asks for increasing, distinct redshifts, so the hit path is not taken there.
-    if (cache.find(z) != cache.end())
-        return cache[z];
-    double distance = 0;
-    double lastZ = 0;
-    double dz = 1e-4;
-    auto it = cache.lower_bound(z);
-    if (it != cache.begin()) {
-        --it;
-        distance = it->second;
-        lastZ = it->first;
-        dz = (z - lastZ) / 100;
+    if (!(c.h0 > 0) || c.omegaM < 0 || c.omegaLambda < 0)
+        throw std::invalid_argument("cosmology: H0 must be positive and the density parameters non-negative");
+    constexpr double kC = 2.99792458e+3 * 100;  // km/s
+    constexpr int kStepsPerInterval = 100;
+    std::vector<double> out(zgrid.size(), 0.0);
+    double integral = 0.0;  // int_0^z dz' / H(z')
+    for (size_t i = 0; i < zgrid.size(); i++) {
+        if (i > 0) {
+            const double from = zgrid[i - 1], to = zgrid[i], h = (to - from) / kStepsPerInterval;
+            for (double z = from; z < to; z += h)
+                integral += 0.5 * h * (1.0 / expansionRate(c, z) + 1.0 / expansionRate(c, z + h));
+        }
+        const double radial = integral * kC;  // Mpc (h = 1 units when H0 = 100)
+        const double omegaK = 1.0 - c.omegaM - c.omegaLambda;
+        if (fabs(omegaK) < 1e-5) {
+            out[i] = radial;
+        } else {  // curved: D_M = R sin(D_C / R) or R sinh(D_C / R), R = c / (H0 sqrt|Omega_K|)
+            const double R = kC / c.h0 / sqrt(fabs(omegaK));
+            out[i] = omegaK < 0 ? R * sinh(radial / R) : R * sin(radial / R);
+        }
     }
-    for (double zi = lastZ; zi < z; zi += dz)  // trapezoids; the float-accumulated loop bound is the reference's
-        distance += 0.5 * dz * (1.0 / Hz(zi) + 1.0 / Hz(zi + dz));
-    cache[z] = distance;
-    return cache[z] * CSPEEDOFLIGHT;
-}
-
-double w0waCDM::transverseComovingDistance(double z) const
-{
-    double D_C = comovingDistance(z);
-    if (fabs(1 - OmegaM - OmegaLambda) < 1e-5)
-        return D_C;
-    double OmegaK = 1.0 - OmegaM - OmegaLambda;
-    double sqrtOmegaK = sqrt(fabs(OmegaK));
-    if (OmegaK < 0)
-        return CSPEEDOFLIGHT / H0 / sqrtOmegaK * sinh(sqrtOmegaK * H0 / CSPEEDOFLIGHT * D_C);
-    return CSPEEDOFLIGHT / H0 / sqrtOmegaK * sin(sqrtOmegaK * H0 / CSPEEDOFLIGHT * D_C);
+    return out;
 }
 
 // ---------------------------------------------------------------- natural cubic spline (GSL cspline's definition:
@@ -175,53 +164,53 @@ int readInput(InputParams &p, const string &name)
     return 0;
 }
 
-// ---------------------------------------------------------------- gadget2io.cpp:613-661
+// ---------------------------------------------------------------- snapshot list (behaviour of gadget2io.cpp:613-661)
+// The list file names one snapshot per entry, sorted by redshift.  Entries are taken until one reaches the source
+// redshift (it is still included) or the file ends; every entry's first sub-file must open; |z| < 1e-5 counts as 0.
 int readRedList(const string &filredshiftlist, vector<double> &snapred, vector<string> &snappath,
                 vector<double> &snapbox, InputParams &p)
 {
-    std::ifstream redlist(filredshiftlist.c_str());
-    double zlast = -999.9;
-    if (!redlist.is_open()) {
-        cerr << " redshift list file redshift_list.txt does not " << endl;
-        cerr << " exist in the Code dir ... check this out      " << endl;
-        cerr << "    I will STOP here !!! " << endl;
+    std::ifstream list(filredshiftlist.c_str());
+    if (!list.is_open()) {
+        cerr << " snapshot list " << filredshiftlist << " cannot be opened: stopping" << endl;
         return 1;
     }
-    Header header{};
-    do {
+    double previous = -999.9;
+    for (;;) {
         string name;
-        redlist >> name;
+        list >> name;  // (at end of file this leaves an empty name, which then fails to open: the reference's behaviour)
         snappath.push_back(name);
+        const string first = p.pathsnap + name + ".0";
         SnapshotFile snap;
-        if (!snap.open(p.pathsnap + name + ".0")) {
-            cerr << "Error in opening the file: " << p.pathsnap + name + ".0" << "!\n\a";
+        if (!snap.open(first)) {
+            cerr << "Error in opening the file: " << first << "!\n\a";
             cerr << name << " not found!" << endl;
             return 1;
         }
-        header = snap.header();
-        if (header.redshift < zlast) {
+        const Header &hdr = snap.header();
+        if (hdr.redshift < previous) {
             cerr << " Snapshots on " << filredshiftlist << " are not sorted!" << endl;
             return 1;
         }
-        zlast = header.redshift;
-        if (std::abs(zlast) < 1e-5)
-            zlast = 0.0;
-        snapred.push_back(zlast);
-        snapbox.push_back(header.boxsize);
-    } while ((header.redshift < p.zs) & (!redlist.eof()));
+        previous = std::abs(hdr.redshift) < 1e-5 ? 0.0 : hdr.redshift;
+        snapred.push_back(previous);
+        snapbox.push_back(hdr.boxsize);
+        if (!(hdr.redshift < p.zs) || list.eof())
+            break;
+    }
     return 0;
 }
 
-// ---------------------------------------------------------------- gadget2io.cpp:34-48
+// ---------------------------------------------------------------- hydro run? (behaviour of gadget2io.cpp:34-48)
+// A Gadget snapshot carries per-particle masses iff some species is present whose table mass is zero.
 void testHydro(InputParams &p, const Header &data)
 {
-    if (p.simType.compare("Gadget") == 0) {
-        int dimmass0 = 0;
-        for (int i = 0; i <= 5; i++)
-            if (data.massarr[i] == 0)
-                dimmass0 += data.npart[i];
-        p.hydro = bool(dimmass0);
-    }
+    if (p.simType != "Gadget")
+        return;
+    bool per_particle = false;
+    for (int t = 0; t < 6; t++)
+        per_particle = per_particle || (data.npart[t] != 0 && data.massarr[t] == 0);
+    p.hydro = per_particle;
 }
 
 // ---------------------------------------------------------------- densitymaps.cpp:9-33
@@ -388,27 +377,29 @@ void randomizeBox(Random &random, Lens &lens, InputParams &p, int numOfLensPerSn
     }
 }
 
-// ---------------------------------------------------------------- densitymaps.cpp:255-283
+// ---------------------------------------------------------------- field of view vs box (behaviour of densitymaps.cpp:255-283)
+// The field of view at the far edge of a plane must fit the box (no lateral replication), or -- with
+// -DUSE_REPLICATION -- the number of lateral box copies needed on each side is worked out.
+static double degToRad(double deg) { return deg / 180. * M_PI; }
+
 int testFov(double fov, double boxl, double Ds, int myid, double &fovradiants)
 {
-    fovradiants = fov / 180. * M_PI;
-    if ((fovradiants)*Ds > boxl && myid == 0) {
-        cerr << " !!Field view too large!!\n !!!I will STOP here!!! " << endl;
-        cerr << " Value set is = " << fov << endl;
-        cerr << " Maximum value allowed " << boxl / Ds * 180. / M_PI << " in degrees " << endl;
-        cerr << " For the lens at " << Ds << endl;
-        return 1;
-    }
-    return 0;
+    fovradiants = degToRad(fov);
+    const bool fits = !(fovradiants * Ds > boxl);
+    if (fits || myid != 0)  // only rank 0 reports (and stops): the reference's behaviour
+        return 0;
+    // ("Field view too large" is the phrase the reference prints: kept for whoever greps the logs)
+    cerr << " !!Field view too large!! " << fov << " deg does not fit the box at comoving distance " << Ds
+         << " (at most " << boxl / Ds * 180. / M_PI << " deg): stopping" << endl;
+    return 1;
 }
 
 void computeReplications(double fov, double boxl, double Ds, int, double &fovradiants, int &nrepperp)
 {
-    fovradiants = fov / 180. * M_PI;
-    if (Ds * tan(fovradiants / 2.0) <= boxl / 2.0)
-        nrepperp = 0;
-    else
-        nrepperp = (int)ceil((Ds * tan(fovradiants / 2) - boxl / 2.0) / boxl);
+    fovradiants = degToRad(fov);
+    const double half_width = Ds * tan(fovradiants / 2.0);  // half extent of the field at distance Ds
+    const double beyond = half_width - boxl / 2.0;          // what sticks out of one box on each side
+    nrepperp = beyond <= 0 ? 0 : (int)ceil(beyond / boxl);
 }
 
 }  // namespace slicer_amd

@@ -1,14 +1,13 @@
 // planner.hpp -- host-side planning of the light cone: the O(nplanes) work that produces
 // the hot path's inputs.  Restates, function by function and with the same names, the reference's
 //   readInput        data.cpp:8-87            readRedList   gadget2io.cpp:613-661   testHydro gadget2io.cpp:34-48
-//   w0waCDM          w0waCDM.{h,cpp}          getSnap / buildPlanes / randomizeBox / testFov / computeReplications
-//                                             densitymaps.cpp:9-283
+//   distance table   w0waCDM.{h,cpp} as used at slicer-v2.cpp:79-86 (transverseDistanceTable, own structure)
+//   getSnap / buildPlanes / randomizeBox / testFov / computeReplications      densitymaps.cpp:9-283
 // The two GSL csplines of slicer-v2.cpp:88-94 become NaturalCubicSpline (GSL is not installed here, so the last
 // bits of interpolated values -- zsimlens, the REDSHIFT key -- are UNPINNED against GSL; plane edges ld/ld2, the
 // snapshot choice and the randomisation do not depend on them except at exact ties).  randomizeBox draws from
 // libc's srand/rand exactly as the reference does, so with the same glibc it yields the same Random plan.
 #pragma once
-#include <map>
 #include <string>
 #include <vector>
 
@@ -20,18 +19,16 @@ constexpr double kPosU = 1.0;            // gadget2io.h:14
 constexpr int kNumberOfLensPerSnap = 4;  // densitymaps.h:23
 constexpr int kNeval = 1000;             // slicer-v2.cpp:5
 
-class w0waCDM {  // w0waCDM.h:20-60
-public:
-    w0waCDM(double H0, double OmegaM, double OmegaLambda, double w0, double wa);
-    double comovingDistance(double z) const;
-    double transverseComovingDistance(double z) const;
-
-private:
-    static constexpr double CSPEEDOFLIGHT = 2.99792458e+3 * 100;
-    double H0, OmegaM, OmegaLambda, w0, wa;
-    mutable std::map<double, double> cache;
-    double Hz(double z) const;
+// Background cosmology of the distance table (the reference keeps these in its w0waCDM class, w0waCDM.h:20-60).
+struct Cosmology {
+    double h0;           // km/s/Mpc (the driver uses 100: distances in Mpc/h)
+    double omegaM, omegaLambda;
+    double w0, wa;       // dark-energy equation of state w(a) = w0 + wa (1 - a)
 };
+double expansionRate(const Cosmology &c, double z);
+// Transverse comoving distances at an increasing redshift grid that starts at 0 (what slicer-v2.cpp:79-86 tabulates),
+// with the reference's integration contract; throws std::invalid_argument on unphysical parameters.
+std::vector<double> transverseDistanceTable(const Cosmology &c, const std::vector<double> &zgrid);
 
 class NaturalCubicSpline {  // stands where gsl_interp_cspline + gsl_spline_eval stand in the reference
 public:

@@ -139,11 +139,16 @@ int main(int argc, char **argv)
     testHydro(p, simdata);
 
     // slicer-v2.cpp:79-96: distance table (h = 1) and the two interpolators
-    w0waCDM cosmo(100.0, simdata.om0, simdata.oml, p.w, 0.0);
-    vector<double> zl(kNeval), dl(kNeval);
-    for (int i = 0; i < kNeval; i++) {
+    const Cosmology cosmo{100.0, simdata.om0, simdata.oml, p.w, 0.0};
+    vector<double> zl(kNeval);
+    for (int i = 0; i < kNeval; i++)
         zl[i] = i * (p.zs + 1.0) / (kNeval - 1);
-        dl[i] = cosmo.transverseComovingDistance(zl[i]);
+    vector<double> dl;
+    try {
+        dl = transverseDistanceTable(cosmo, zl);
+    } catch (const std::exception &e) {
+        cerr << e.what() << endl;
+        return 1;
     }
     NaturalCubicSpline getDl, getZl;
     getDl.init(zl, dl);
