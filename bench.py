@@ -411,7 +411,6 @@ def main():
     if rank == 0 and ref_maps:
         import numpy as np
         n_par = a.cpu_particles
-        S0.set_stream(0)
         S0.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False)
         S0.file_begin([0, n_par, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
         buf = torch.empty(n_par * 3, dtype=torch.float32, device="cuda")

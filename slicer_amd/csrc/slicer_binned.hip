@@ -445,9 +445,18 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     }
 }
 
+// the k-fold sequential f32 sum s <- fl(s + m) of utilities.cpp:75: what a pixel of the reference's per-file NGP map holds
+__device__ __forceinline__ float ngp_seq_sum(unsigned k, float m)
+{
+    float s = 0.0f;
+    for (unsigned j = 0; j < k; j++)
+        s = s + m;
+    return s;
+}
+
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
-                                                             TileItems I)
+                                                             TileItems I, NgpFold F)
 {
     using acc_t = typename AccT<ACC>::type;
     using lds_t = typename AccT<ACC>::lds;
@@ -488,6 +497,22 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W);
     __syncthreads();
 
+    if (ACC == kCountU32 && F.on && nparts == 1) {
+        // NGP fold in place: this workgroup is the only one that touches these pixels in this launch (NGP records hit
+        // cells of their own tile only, and the tile is not split), so plain read-modify-writes in file order are exact
+        float *tot = F.tot[plane], *toti = F.toti[plane];
+        for (int i = tid; i < cells; i += kTileBlock) {
+            const unsigned k = (unsigned)tile[i];
+            if (k == 0)
+                continue;
+            const size_t idx = (size_t)(x0 - 1 + i % W) + (size_t)nn * (size_t)(y0 - 1 + i / W);
+            const float v = ngp_seq_sum(k, F.m);
+            tot[idx] = tot[idx] + v;
+            if (toti)
+                toti[idx] = toti[idx] + v;
+        }
+        return;
+    }
     // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
     acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
     for (int i = tid; i < cells; i += kTileBlock) {
@@ -499,6 +524,40 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         if (px < 0 || px >= nn || py < 0 || py >= nn)
             continue;
         atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)v);
+    }
+}
+
+// NGP fold of the tiles that were split over several workgroups (their parts added counts to the global count map):
+// one workgroup per listed tile (the list entries with part == 1 name every split bin exactly once).
+__global__ __launch_bounds__(256) void k_fold_heavy_tiles(PassParams P, BinGeom G, Targets T, TileItems I, NgpFold F)
+{
+    const unsigned n = *I.n_extra;
+    for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint2 item = I.extra[j];
+        if (item.y != 1)
+            continue;
+        const int bin = (int)item.x;
+        const int unit = bin / G.tiles_per_unit, t = bin % G.tiles_per_unit;
+        const int plane = unit / G.units_per_plane, band = unit % G.units_per_plane;
+        const int x0 = (t % G.ntx) << G.tw_log2;
+        const int y0 = (band * G.rows_per_unit + t / G.ntx) << G.th_log2;
+        const int tw = 1 << G.tw_log2, th = 1 << G.th_log2;
+        unsigned *cnt = reinterpret_cast<unsigned *>(T.acc[plane]);
+        float *tot = F.tot[plane], *toti = F.toti[plane];
+        for (int i = threadIdx.x; i < tw * th; i += 256) {
+            const int px = x0 + i % tw, py = y0 + i / tw;
+            if (px >= P.nn || py >= P.nn)
+                continue;
+            const size_t idx = (size_t)px + (size_t)P.nn * (size_t)py;
+            const unsigned k = cnt[idx];
+            if (k == 0)
+                continue;
+            cnt[idx] = 0;
+            const float v = ngp_seq_sum(k, F.m);
+            tot[idx] = tot[idx] + v;
+            if (toti)
+                toti[idx] = toti[idx] + v;
+        }
     }
 }
 
@@ -528,7 +587,7 @@ hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, i
     const size_t lds = scatter_lds_bytes(G, has_mass);
     const int items = G.n_units * 8 * ((nblocks + 7) / 8);
     const int nwg = std::min(items, std::max(8, max_workgroups / 8 * 8));
-    const int count_planes = cfg.mas == kTSC ? n_planes : 0;
+    const int count_planes = n_planes;  // records per plane -> selected-entry counters (NGP adds its dropped ones in K1)
     hipError_t e;
     if (has_mass) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_scatter<true>),
@@ -556,7 +615,7 @@ size_t tile_lds_bytes(const BinGeom &G, int acc)
 
 template <int MAS, int ACC>
 static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const BinGeom &G, const PendingList &L,
-                            const Targets &T, const TileItems &I, unsigned max_items, hipStream_t s)
+                            const Targets &T, const TileItems &I, const NgpFold &F, unsigned max_items, hipStream_t s)
 {
     const size_t lds = tile_lds_bytes(G, ACC);
 #define K4(P2_, HM_)                                                                                             \
@@ -568,7 +627,7 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
             if (e != hipSuccess)                                                                                 \
                 return e;                                                                                        \
         }                                                                                                        \
-        kern<<<max_items, kTileBlock, lds, s>>>(L, P, G, T, I);                                         \
+        kern<<<max_items, kTileBlock, lds, s>>>(L, P, G, T, I, F);                                      \
     } while (0)
     if (pow2) {
         if (has_mass) K4(true, true); else K4(true, false);
@@ -586,7 +645,8 @@ size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles)
 }
 
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
-                               const Targets &T, void *items_ws, unsigned epoch, uint64_t total_particles, hipStream_t s)
+                               const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,
+                               uint64_t total_particles, hipStream_t s)
 {
     // total_particles bounds the number of records (each particle emits at most one on this path).  Workspace:
     // two counters (used alternately: launch `epoch` reads [epoch & 1] and zeroes the other one) | nparts | extra
@@ -600,14 +660,20 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
     k_build_items<<<(G.nbins + 255) / 256, 256, 0, s>>>(L, G.nbins, I);
     const bool pow2 = P.pow2 != 0;
     if (cfg.mas == kNGP) {
-        if (cfg.acc == kCountU32)
-            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, max_items, s);
-        return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
+        if (cfg.acc == kCountU32) {
+            hipError_t e = launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, F, max_items, s);
+            if (e == hipSuccess && F.on) {
+                k_fold_heavy_tiles<<<64, 256, 0, s>>>(P, G, T, I, F);
+                e = hipGetLastError();
+            }
+            return e;
+        }
+        return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }
     switch (cfg.acc) {
-    case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
-    case kF64: return launch_k4<kTSC, kF64>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
-    case kFixed64: return launch_k4<kTSC, kFixed64>(pow2, cfg.has_mass, P, G, L, T, I, max_items, s);
+    case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
+    case kF64: return launch_k4<kTSC, kF64>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
+    case kFixed64: return launch_k4<kTSC, kFixed64>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     default: return hipErrorInvalidValue;
     }
 }

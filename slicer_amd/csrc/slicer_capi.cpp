@@ -64,6 +64,7 @@ struct slicer_handle_s {
     int algo_mask = 0;            // bit (1 << SLICER_ALGO_*) of every algorithm that ran in this pass; bit 3 = thinning
     bool neg_remote = false;      // another rank reported the negativity guard (slicer_reduce_meta_set)
     int file_mode[6] = {};        // NGP fold mode of the current file
+    bool file_partial_flush[6] = {};  // NGP: part of this file's records of the species were flushed before file_end
     float file_mconst[6] = {};
     int fixed_exp[6] = {};
     int fixed_exp_shared = 0;
@@ -555,6 +556,15 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
             A.face = f;
     A.rcase = P.rcase;
     A.n_planes = P.n_planes;
+    {
+        // expected fraction of particles that reach the projection: the slabs' share of the unit box depth
+        // (positions are uniform in z to first order); SLICER_K1_STACK=0/1 overrides
+        double depth = 0;
+        for (int p = 0; p < P.n_planes; p++)
+            depth += std::max(0.0, std::min<double>(P.zhi[p], P.rcase + 1.0) - std::max<double>(P.zlo[p], P.rcase));
+        const int env = env_int("SLICER_K1_STACK", -1);
+        A.stack = env >= 0 ? env : (depth < 0.6 ? 1 : 0);
+    }
     for (int p = 0; p < 4; p++)
         A.zlo[p] = P.zlo[p];  // +inf beyond n_planes (make_params)
     A.zlast = P.zhi[P.n_planes - 1];
@@ -601,10 +611,32 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, c
 }
 
 // Deposit every pending (binned) chunk with one tile-kernel launch.
-int flush_pending(slicer_handle h)
+int flush_pending(slicer_handle h, bool at_file_end = false)
 {
     if (h->pend.n == 0)
         return SLICER_OK;
+    // NGP fast path (see NgpFold): constant mass, the sub-file holds this one species only, and this flush carries all
+    // of its records (a flush forced in mid-file does not: its counts are partial)
+    NgpFold F;
+    memset(&F, 0, sizeof F);
+    const int ptype = h->pend_key / 2;
+    if (h->pend_cfg.mas == kNGP && h->pend_cfg.acc == kCountU32 && h->pend_key < 12) {
+        int species = 0;
+        for (int t = 0; t < 6; t++)
+            species += h->file.npart[t] > 0;
+        if (at_file_end && species == 1 && h->file.npart[ptype] > 0 && !h->file_partial_flush[ptype] &&
+            !env_int("SLICER_NGP_GENERAL")) {
+            F.on = 1;
+            F.m = h->file_mconst[ptype];
+            for (int p = 0; p < h->desc.n_planes; p++) {
+                F.tot[p] = (float *)h->planes[p].tot.p;
+                F.toti[p] = h->desc.want_type_maps ? (float *)h->planes[p].toti[ptype].p : nullptr;
+            }
+            h->file_mode[ptype] = 0;  // folded here: slicer_file_end has nothing left to do for this species
+        } else {
+            h->file_partial_flush[ptype] = true;
+        }
+    }
     bool fresh = false;
     int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles), &fresh);
     if (rc)
@@ -615,7 +647,7 @@ int flush_pending(slicer_handle h)
     }
     {
         ProfScope ps(h, KN_TILE);
-        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, h->w_items.p,
+        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, F, h->w_items.p,
                                       h->items_epoch++, h->pend_particles, h->stream));
     }
     h->pend.n = 0;
@@ -966,8 +998,10 @@ int slicer_file_begin(slicer_handle h, const slicer_file_desc *file)
             return fail(h, SLICER_ERR_ARG, "sgn[%d] = %d is not +-1", a, file->sgn[a]);
     h->file = *file;
     h->in_file = true;
-    for (int t = 0; t < 6; t++)
+    for (int t = 0; t < 6; t++) {
         h->file_mode[t] = 0;
+        h->file_partial_flush[t] = false;
+    }
     return SLICER_OK;
 }
 
@@ -1063,7 +1097,7 @@ int slicer_file_end(slicer_handle h)
     h->in_file = false;
     if (h->desc.mas == SLICER_MAS_NGP) {
         // the per-file fold needs this file's complete counts
-        int rcf = flush_pending(h);
+        int rcf = flush_pending(h, true);
         if (rcf)
             return rcf;
         bool any = false;

@@ -120,6 +120,7 @@ struct K1Args {
     // zlast = zhi[n_planes - 1]
     float zlo[4], zlast;
     int n_planes, vec, ngp;
+    int stack;                 // compact survivors through the wave stack before projecting (few survivors) or not
     // conservative FOV pre-test
     float k_ra, eps_ra, k_dec, eps_dec;
     // projection + grid (power-of-two maps)
@@ -155,7 +156,19 @@ struct PendingList {
     float sm_const[kMaxPending];  // sqrtf(mconst)
 };
 size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles);
+// NGP with one constant mass, all records of a (sub-file, species) in one flush, the sub-file holding no other species:
+// the tile kernel folds its counts straight into the f32 maps while the tile is in LDS -- pixel value = the k-fold
+// sequential f32 sum s <- fl(s + m) (utilities.cpp:75), tot += it, toti += it (densitymaps.cpp:511-513 with five zero
+// maps) -- instead of adding them to a global count map that a map-wide pass folds afterwards.  Tiles split over
+// several workgroups (halo cores) still go through the count map; k_fold_heavy_tiles folds just those.
+struct NgpFold {
+    int on;
+    float m;
+    float *tot[kMaxPlanes];
+    float *toti[kMaxPlanes];  // or nullptr (per-type maps not kept)
+};
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
-                               const Targets &T, void *items_ws, unsigned epoch, uint64_t total_particles, hipStream_t s);
+                               const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,
+                               uint64_t total_particles, hipStream_t s);
 
 }  // namespace slicer

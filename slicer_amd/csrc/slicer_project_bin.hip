@@ -45,7 +45,11 @@ namespace {
 #define SLICER_K1_WAVES_PER_SIMD 6
 #endif
 constexpr int kK1Block = SLICER_K1_BLOCK;  // 12 waves, two workgroups per CU at 32768 particles each
-constexpr int kPerThread = 4;              // particles per lane and round (three dwordx4 loads)
+#ifndef SLICER_K1_PER_THREAD
+#define SLICER_K1_PER_THREAD 4
+#endif
+constexpr int kPerThread = SLICER_K1_PER_THREAD;  // particles per lane and round: 4 (three dwordx4 loads) or 2 (three dwordx2)
+static_assert(kPerThread == 4 || kPerThread == 2, "load_round handles 2 or 4 particles per lane");
 constexpr int kRound = kK1Block * kPerThread;
 constexpr int kWaves = kK1Block / 64;
 constexpr int kWaveQ = 64 * kPerThread + 64;  // stack capacity per wave: one round + a remainder < 64
@@ -54,12 +58,19 @@ __device__ __forceinline__ void load_round(bool vec, const float *__restrict__ p
                                            float (&rx)[kPerThread], float (&ry)[kPerThread], float (&rz)[kPerThread])
 {
     if (vec && nvalid == kPerThread) {  // 16-byte aligned block: four particles = three dwordx4 loads
-        const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
-        const float4 a = p4[0], b = p4[1], c = p4[2];
-        rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
-        rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
-        rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
-        rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
+        if constexpr (kPerThread == 4) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
+            const float4 a = p4[0], b = p4[1], c = p4[2];
+            rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
+            rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
+            rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
+            rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
+        } else {  // two particles = three dwordx2 loads (the lane's 24 bytes are 8-byte aligned)
+            const float2 *p2 = reinterpret_cast<const float2 *>(pos + 3 * i0);
+            const float2 a = p2[0], b = p2[1], c = p2[2];
+            rx[0] = a.x; ry[0] = a.y; rz[0] = b.x;
+            rx[1] = b.y; ry[1] = c.x; rz[1] = c.y;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
@@ -147,9 +158,9 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
     bool emit = valid;
     if (ngp) {
         emit = valid && gx >= 0 && gx < nn && gy >= 0 && gy < nn;  // utilities.cpp:74 drop rule
-        // NGP drops off-grid entries after selection: count the selected ones here (TSC emits every selected entry, so
-        // k_scan_bins takes the counters from the bin totals)
-        if (valid)
+        // The selected-entry counters come from the bin totals (sort kernel's prologue): every emitted record is a
+        // selected entry.  NGP drops the off-grid ones (border ring, ~0.5 %) after selection: only those are counted here.
+        if (valid && !emit)
             atomicAdd(&s_cnt[plane], 1u);
     }
     // border-ring entries of TSC (g = -1 or nn) still feed the edge pixels: binned with the clamped cell
@@ -196,7 +207,38 @@ __device__ SLICER_SLOWPATH bool process_exact(const K1Kernarg *Kk, unsigned *s_h
     return neg;
 }
 
-template <int FACE, int SERIES>
+// Fast projection (A3) of one selected entry per lane + emission; entries it cannot decide are noted for the epilogue.
+template <int SERIES>
+__device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
+                                             unsigned *s_exc, unsigned *s_nexc, bool have, float ex, float ey, float ez,
+                                             unsigned tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
+{
+    float xs = 0.f, ys = 0.f;
+    // A3 (densitymaps.cpp:382-386, utilities.cpp:23-25) to a few ulp: q = X / d and t = Y / Z through one cubic step on
+    // the hardware reciprocal (square root); asin / atan by the series of slicer_device.hpp
+    const double X = (double)ex - 0.5, Y = (double)ey - 0.5, Z = (double)ez;
+    const double S = fma(X, X, fma(Y, Y, Z * Z));
+    const double sn = X * rsqrt_fast(S);
+    const double tn = Y * rcp_fast(Z);
+    const double dec = asin_small<SERIES>(sn), ra = atan_small<SERIES>(tn);
+    const double adec = fabs(dec), ara = fabs(ra);
+    // undecided: outside the series' range (tiny z), or within the error window of the FOV limit or of an f32 rounding
+    // tie of a map coordinate
+    const double sx = fma(dec, A.inv_fov, 0.5), sy = fma(ra, A.inv_fov, 0.5);
+    const bool dx = round_decided(sx, kMapWindow, xs), dy = round_decided(sy, kMapWindow, ys);
+    const bool undecided = !(fabs(sn) <= A.series_max && fabs(tn) <= A.series_max && ez > 0.0f) ||
+                           fabs(adec - A.lim) <= kAngWindow || fabs(ara - A.lim) <= kAngWindow || !dx || !dy;
+    if (have && undecided)  // rare: noted for the exact epilogue
+        s_exc[min(atomicAdd(s_nexc, 1u), kExcCap - 1)] = tag >> 3;
+    const bool valid = have && !undecided && adec <= A.lim && ara <= A.lim;
+    emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, tag >> 3, b0, out_wg, unit_stride);
+}
+
+// STACK: survivors of the slab / pre-test are compacted through the wave stack so that the projection runs on full
+// waves (pays when few particles survive: one plane per pass keeps ~20 %); !STACK: the projection runs in place on the
+// lanes that survive (pays when most do: the four planes of a replication keep ~78 %, and the LDS traffic and the
+// write -> read round trips of the stack cost more than the idle lanes).
+template <int FACE, int SERIES, bool STACK>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin_fast(K1Kernarg K)
 {
     const K1Args &A = K.A;  // K.P is read through the kernarg segment by the exact epilogue only
@@ -288,45 +330,32 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             if (live && off)  // rare: noted for the exact epilogue
                 s_exc[min(atomicAdd(&s_nexc, 1u), kExcCap - 1)] = (unsigned)(i0 + k - b0);
             const unsigned long long mask = __ballot(sel);
-            if (sel) {
-                const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                const unsigned tag = (unsigned)plane | ((unsigned)(i0 + k - b0) << 3);
-                q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
+            const unsigned tag = (unsigned)plane | ((unsigned)(i0 + k - b0) << 3);
+            if (STACK) {
+                if (sel) {
+                    const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                    q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
+                }
+                top += (unsigned)__popcll(mask);
+            } else if (mask != 0ull) {
+                project_emit<SERIES>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, sel, x, y, z, tag, b0, out_wg, unit_stride);
             }
-            top += (unsigned)__popcll(mask);
         }
-        lds_fence();
-
-        // ---- fp64 projection on full waves popped from the stack ----
-        while (top >= 64u || (!more && top > 0u)) {
-            const unsigned take = top >= 64u ? 64u : top;
-            float xs = 0.f, ys = 0.f;
-            float4 ent = make_float4(0.5f, 0.5f, 1.0f, 0.0f);
-            const bool have = lane < take;
-            if (have)
-                ent = q4[top - take + lane];
-            top -= take;
-            const unsigned tag = __float_as_uint(ent.w);
-            // A3 (densitymaps.cpp:382-386, utilities.cpp:23-25) to a few ulp: q = X / d and t = Y / Z through one cubic
-            // step on the hardware reciprocal (square root); asin / atan by the series of slicer_device.hpp
-            const double X = (double)ent.x - 0.5, Y = (double)ent.y - 0.5, Z = (double)ent.z;
-            const double S = fma(X, X, fma(Y, Y, Z * Z));
-            const double sn = X * rsqrt_fast(S);
-            const double tn = Y * rcp_fast(Z);
-            const double dec = asin_small<SERIES>(sn), ra = atan_small<SERIES>(tn);
-            const double adec = fabs(dec), ara = fabs(ra);
-            // undecided: outside the series' range (tiny z), or within the error window of the FOV limit or of an f32
-            // rounding tie of a map coordinate
-            const double sx = fma(dec, A.inv_fov, 0.5), sy = fma(ra, A.inv_fov, 0.5);
-            const bool dx = round_decided(sx, kMapWindow, xs), dy = round_decided(sy, kMapWindow, ys);
-            const bool undecided = !(fabs(sn) <= A.series_max && fabs(tn) <= A.series_max && ent.z > 0.0f) ||
-                                   fabs(adec - A.lim) <= kAngWindow || fabs(ara - A.lim) <= kAngWindow || !dx || !dy;
-            if (have && undecided)  // rare: noted for the exact epilogue
-                s_exc[min(atomicAdd(&s_nexc, 1u), kExcCap - 1)] = tag >> 3;
-            const bool valid = have && !undecided && adec <= A.lim && ara <= A.lim;
-            emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, tag >> 3, b0, out_wg, unit_stride);
+        if (STACK) {
+            lds_fence();
+            // ---- fp64 projection on full waves popped from the stack ----
+            while (top >= 64u || (!more && top > 0u)) {
+                const unsigned take = top >= 64u ? 64u : top;
+                float4 ent = make_float4(0.5f, 0.5f, 1.0f, 0.0f);
+                const bool have = lane < take;
+                if (have)
+                    ent = q4[top - take + lane];
+                top -= take;
+                project_emit<SERIES>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, have, ent.x, ent.y, ent.z,
+                                     __float_as_uint(ent.w), b0, out_wg, unit_stride);
+            }
+            lds_fence();
         }
-        lds_fence();
 
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
@@ -450,8 +479,9 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 }
             }
             top -= take;
-            // selected-entry counters: TSC takes them from the bin totals (k_scan_bins), NGP counts here
-            if (MAS == kNGP && valid)
+            // selected-entry counters: from the bin totals (sort kernel's prologue); NGP adds the selected entries it
+            // drops as off-grid here
+            if (MAS == kNGP && valid && !emit)
                 atomicAdd(&s_cnt[plane], 1u);
             if (emit) {
                 const unsigned o = atomicAdd(&s_out[unit], 1u);
@@ -626,17 +656,19 @@ static hipError_t launch_k1_fast(bool s9, int nb, size_t lds, const PassParams &
     K1Kernarg K;
     K.P = P;
     K.A = A;
-    if (s9) {
-        auto kern = k_project_bin_fast<FACE, 9>;
-        if ((e = set_lds(kern, lds)) != hipSuccess)
-            return e;
-        kern<<<nb, kK1Block, lds, s>>>(K);
+#define K1F(S_, ST_)                                                                  \
+    do {                                                                              \
+        auto kern = k_project_bin_fast<FACE, S_, ST_>;                                \
+        if ((e = set_lds(kern, lds)) != hipSuccess)                                   \
+            return e;                                                                 \
+        kern<<<nb, kK1Block, lds, s>>>(K);                                            \
+    } while (0)
+    if (A.stack) {
+        if (s9) K1F(9, true); else K1F(15, true);
     } else {
-        auto kern = k_project_bin_fast<FACE, 15>;
-        if ((e = set_lds(kern, lds)) != hipSuccess)
-            return e;
-        kern<<<nb, kK1Block, lds, s>>>(K);
+        if (s9) K1F(9, false); else K1F(15, false);
     }
+#undef K1F
     return hipGetLastError();
 }
 
