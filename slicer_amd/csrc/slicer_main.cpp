@@ -1,23 +1,31 @@
-// slicer_main.cpp -- `SLICER_amd InputParams.ini`: the Gadget branch of slicer-v2.cpp (:23-229) on one MI355X, without
-// MPI.  Planning (planner.cpp) -> plane loop -> createDensityMaps-equivalent passes over the C ABI -> writeMaps.
+// slicer_main.cpp -- `SLICER_amd InputParams.ini [--devices 0-7]`: the Gadget branch of slicer-v2.cpp (:23-229) on the
+// MI355X GPUs of one node, without MPI.  Planning (planner.cpp) -> plane loop -> createDensityMaps-equivalent passes
+// over the C ABI -> writeMaps.  With several devices one host thread drives each GPU through its own handle: the
+// sub-files of every snapshot are split over the devices in the reference's contiguous ranges (slicer-v2.cpp:162-175),
+// the partial maps are summed onto device 0 in the accumulator type (slicer-v2.cpp:214-217 -> RCCL over xGMI,
+// include/slicer_amd_rccl.h), and device 0's thread writes the FITS files -- byte-identical to a one-device run with
+// --accum fixed64, within the f32 reorder bound otherwise.
 // Differences from the reference driver, all opt-out:
 //   * the planes cut from one box replication (same snapshot, same Random entry, same rcase) are built in ONE pass
 //     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
 //   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
 //     partinplanes runs write their per-type files;                                      --reference-counts disables
 //   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass.
+#include <dlfcn.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <valarray>
 #include <vector>
 
-#include "../../include/slicer_amd.h"
+#include "../../include/slicer_amd_rccl.h"
 #include "fits_writer.hpp"
 #include "gadget2_reader.hpp"
 #include "planner.hpp"
@@ -85,16 +93,151 @@ int fill_from_file(void *user, float *dst_pos, float *dst_mass, uint64_t first, 
     return 0;
 }
 
+// "0-3", "0,2,5", "1": HIP device ordinals, one rank each
+vector<int> parse_devices(const string &spec)
+{
+    vector<int> out;
+    size_t i = 0;
+    while (i < spec.size()) {
+        size_t j = spec.find(',', i);
+        if (j == string::npos)
+            j = spec.size();
+        const string tok = spec.substr(i, j - i);
+        const size_t dash = tok.find('-');
+        if (dash != string::npos && dash > 0) {
+            for (int d = atoi(tok.substr(0, dash).c_str()); d <= atoi(tok.substr(dash + 1).c_str()); d++)
+                out.push_back(d);
+        } else if (!tok.empty()) {
+            out.push_back(atoi(tok.c_str()));
+        }
+        i = j + 1;
+    }
+    return out;
+}
+
+// libslicer_amd_rccl.so is only needed (and only loaded) when more than one device takes part
+struct RcclApi {
+    void *lib = nullptr;
+    int (*init_all)(slicer_rccl_comm *, int, const int *) = nullptr;
+    int (*destroy)(slicer_rccl_comm) = nullptr;
+    int (*plane_reduce)(slicer_handle, slicer_rccl_comm, int, int) = nullptr;
+    const char *(*last_error)(void) = nullptr;
+    bool load()
+    {
+        lib = dlopen("libslicer_amd_rccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) {
+            cerr << "slicer_amd: " << dlerror() << endl;
+            return false;
+        }
+        init_all = (decltype(init_all))dlsym(lib, "slicer_rccl_comm_init_all");
+        destroy = (decltype(destroy))dlsym(lib, "slicer_rccl_comm_destroy");
+        plane_reduce = (decltype(plane_reduce))dlsym(lib, "slicer_rccl_plane_reduce");
+        last_error = (decltype(last_error))dlsym(lib, "slicer_rccl_last_error");
+        return init_all && destroy && plane_reduce && last_error;
+    }
+};
+
+// One rank = one GPU = one handle (+ its communicator).
+struct Rank {
+    int device = 0;
+    slicer_handle h = nullptr;
+    slicer_rccl_comm comm = nullptr;
+    int rc = 0;
+};
+
+// The rank sum without RCCL (--reduce host): accumulators through host memory, summed in their own type onto rank 0.
+// The same protocol as slicer_rccl_plane_reduce (include/slicer_amd.h "cross-rank sum"); it exists so that the
+// multi-rank driver can be exercised where the ranks cannot form an RCCL clique (two handles on one GPU in the tests).
+int host_plane_reduce(vector<Rank> &ranks, int npix, int n_planes)
+{
+    slicer_reduce_meta comb;
+    for (int i = 0; i < SLICER_REDUCE_META_INTS; i++)
+        comb.v[i] = INT32_MIN;
+    for (auto &r : ranks) {
+        slicer_reduce_meta m;
+        if (slicer_reduce_meta_get(r.h, &m) != SLICER_OK) {
+            cerr << "slicer_amd: " << slicer_last_error(r.h) << endl;
+            return 1;
+        }
+        for (int i = 0; i < SLICER_REDUCE_META_INTS; i++)
+            comb.v[i] = std::max(comb.v[i], m.v[i]);
+    }
+    for (auto &r : ranks)
+        if (slicer_reduce_meta_set(r.h, &comb) != SLICER_OK) {
+            cerr << "slicer_amd: " << slicer_last_error(r.h) << endl;
+            return 1;
+        }
+    const size_t n = (size_t)npix * (size_t)npix;
+    vector<unsigned char> sum, part;
+    for (int p = 0; p < n_planes; p++) {
+        void *acc0[7];
+        int32_t elem = 0;
+        if (slicer_plane_accumulators(ranks[0].h, p, acc0, &elem) != SLICER_OK)
+            return 1;
+        const size_t esz = elem == SLICER_ELEM_F32 ? 4 : 8;
+        for (int s = 0; s < 7; s++) {
+            if (!acc0[s])
+                continue;
+            sum.resize(n * esz);
+            part.resize(n * esz);
+            if (slicer_copy_to_host(ranks[0].h, sum.data(), acc0[s], n * esz) != SLICER_OK)
+                return 1;
+            for (size_t k = 1; k < ranks.size(); k++) {
+                void *acc[7];
+                int32_t e2 = 0;
+                if (slicer_plane_accumulators(ranks[k].h, p, acc, &e2) != SLICER_OK || e2 != elem || !acc[s] ||
+                    slicer_copy_to_host(ranks[k].h, part.data(), acc[s], n * esz) != SLICER_OK)
+                    return 1;
+                if (elem == SLICER_ELEM_F32) {
+                    float *a = (float *)sum.data();
+                    const float *b = (const float *)part.data();
+                    for (size_t i = 0; i < n; i++)
+                        a[i] = a[i] + b[i];
+                } else if (elem == SLICER_ELEM_F64) {
+                    double *a = (double *)sum.data();
+                    const double *b = (const double *)part.data();
+                    for (size_t i = 0; i < n; i++)
+                        a[i] = a[i] + b[i];
+                } else {
+                    uint64_t *a = (uint64_t *)sum.data();
+                    const uint64_t *b = (const uint64_t *)part.data();
+                    for (size_t i = 0; i < n; i++)
+                        a[i] += b[i];
+                }
+            }
+            if (slicer_copy_to_device(ranks[0].h, acc0[s], sum.data(), n * esz) != SLICER_OK)
+                return 1;
+        }
+        uint64_t *c0 = nullptr, tot[6], one[6];
+        if (slicer_plane_device_counts(ranks[0].h, p, &c0) != SLICER_OK ||
+            slicer_copy_to_host(ranks[0].h, tot, c0, sizeof tot) != SLICER_OK)
+            return 1;
+        for (size_t k = 1; k < ranks.size(); k++) {
+            uint64_t *ck = nullptr;
+            if (slicer_plane_device_counts(ranks[k].h, p, &ck) != SLICER_OK ||
+                slicer_copy_to_host(ranks[k].h, one, ck, sizeof one) != SLICER_OK)
+                return 1;
+            for (int t = 0; t < 6; t++)
+                tot[t] += one[t];
+        }
+        if (slicer_copy_to_device(ranks[0].h, c0, tot, sizeof tot) != SLICER_OK)
+            return 1;
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
 {
-    string inifile, plan_path;
+    string inifile, plan_path, devices_spec, reduce_mode = "rccl";
     int device = 0, mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32;
     bool plan_only = false, single_plane = false, reference_counts = false, replication = false;
     for (int i = 1; i < argc; i++) {
         string a = argv[i];
         if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--devices" && i + 1 < argc) devices_spec = argv[++i];
+        else if (a == "--reduce" && i + 1 < argc) reduce_mode = argv[++i];  // rccl (default) | host
         else if (a == "--ngp") mas = SLICER_MAS_NGP;
         else if (a == "--accum" && i + 1 < argc) {
             string v = argv[++i];
@@ -177,11 +320,31 @@ int main(int argc, char **argv)
     if (p.snopt != 0)
         single_plane = true;  // thinning consumes libc rand() plane by plane (densitymaps.cpp:387-397)
 
-    slicer_handle h = nullptr;
-    if (slicer_create(device, 1ull << 24, &h) != SLICER_OK) {
-        cerr << "slicer_amd: " << slicer_last_error(nullptr) << endl;
-        return 1;
+    vector<int> devs = devices_spec.empty() ? vector<int>{device} : parse_devices(devices_spec);
+    if (devs.empty() || (reduce_mode != "rccl" && reduce_mode != "host")) {
+        cerr << "bad --devices / --reduce" << endl;
+        return 2;
     }
+    vector<Rank> ranks(devs.size());
+    for (size_t r = 0; r < devs.size(); r++) {
+        ranks[r].device = devs[r];
+        if (slicer_create(devs[r], 1ull << 24, &ranks[r].h) != SLICER_OK) {
+            cerr << "slicer_amd: " << slicer_last_error(nullptr) << endl;
+            return 1;
+        }
+    }
+    const int nranks = (int)ranks.size();
+    RcclApi rccl;
+    if (nranks > 1 && reduce_mode == "rccl") {
+        vector<slicer_rccl_comm> comms(nranks);
+        if (!rccl.load() || rccl.init_all(comms.data(), nranks, devs.data()) != SLICER_OK) {
+            cerr << "slicer_amd: cannot set up RCCL over the devices: " << (rccl.last_error ? rccl.last_error() : "") << endl;
+            return 1;
+        }
+        for (int r = 0; r < nranks; r++)
+            ranks[r].comm = comms[r];
+    }
+    slicer_handle h = ranks[0].h;  // device 0 of the list is the root: it ends up with the sums and writes the maps
     cout << " Now loop on " << lens.nplanes << " planes " << endl;
     float rcase = 0.0f;  // slicer-v2.cpp:137
     int isnap = 0;
@@ -241,64 +404,85 @@ int main(int argc, char **argv)
             d.ld2[k] = lens.ld2[todo[k]];
             d.nrepperp[k] = lens.nrepperp[todo[k]];
         }
-        if (slicer_plane_begin(h, &d) != SLICER_OK) {
-            cerr << "slicer_amd: " << slicer_last_error(h) << endl;
-            rc_all = 1;
-            break;
-        }
-        for (int ff = 0; ff < simhdr.numfiles && rc_all == 0; ff++) {
-            char suffix[32];
-            snprintf(suffix, sizeof suffix, "%i", ff);
-            SnapshotFile snap;
-            if (!snap.open(File + "." + suffix)) {
-                cerr << "Error in opening the file: " << File << "." << suffix << "!\n\a";
-                rc_all = 1;
-                break;
-            }
-            const Header &data = snap.header();
-            long pos_off = 0, pos_bytes = 0;
-            vector<float> mass[6];
-            if (!snap.locate_block("POS ", pos_off, pos_bytes) || (p.hydro && !snap.read_masses(mass))) {
-                cerr << "slicer_amd: cannot read POS / MASS of " << snap.path() << endl;
-                rc_all = 1;
-                break;
-            }
-            slicer_file_desc f{};
-            for (int t = 0; t < 6; t++) {
-                f.npart[t] = data.npart[t];
-                f.massarr[t] = data.massarr[t];
-            }
-            f.boxsize = data.boxsize;
-            f.sgn[0] = random.sgnX[isnap];
-            f.sgn[1] = random.sgnY[isnap];
-            f.sgn[2] = random.sgnZ[isnap];
-            f.face = random.face[isnap];
-            f.center[0] = random.x0[isnap];
-            f.center[1] = random.y0[isnap];
-            f.center[2] = random.z0[isnap];
-            f.rcase = rcase;
-            if (slicer_file_begin(h, &f) != SLICER_OK) {
-                cerr << "slicer_amd: " << slicer_last_error(h) << endl;
-                rc_all = 1;
-                break;
-            }
-            size_t off = 0;
-            for (int t = 0; t < 6 && rc_all == 0; t++) {
-                const size_t n = data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
-                if (n) {
-                    const float *m = (p.hydro && data.massarr[t] == 0 && !mass[t].empty()) ? mass[t].data() : nullptr;
-                    Span span{&snap, pos_off + (long)(12 * off), m};
-                    if (slicer_deposit_stream(h, t, n, m != nullptr, fill_from_file, &span) != SLICER_OK) {
-                        cerr << "slicer_amd: " << slicer_last_error(h) << endl;
-                        rc_all = 1;
-                    }
+        // one rank's share of the pass: its contiguous range of sub-files (slicer-v2.cpp:162-175: numfiles / nranks each,
+        // the last rank takes the remainder), then the rank sum
+        auto run_rank = [&](int r) {
+            Rank &R = ranks[r];
+            slicer_handle hr = R.h;
+            R.rc = 0;
+            auto failed = [&](const char *what) {
+                cerr << "slicer_amd (device " << R.device << "): " << what << ": " << slicer_last_error(hr) << endl;
+                R.rc = 1;
+            };
+            if (slicer_plane_begin(hr, &d) != SLICER_OK)
+                return failed("plane_begin");
+            const int per = simhdr.numfiles / nranks;
+            const int ffmin = r * per, ffmax = (r == nranks - 1) ? simhdr.numfiles : (r + 1) * per;
+            for (int ff = ffmin; ff < ffmax && R.rc == 0; ff++) {
+                char suffix[32];
+                snprintf(suffix, sizeof suffix, "%i", ff);
+                SnapshotFile snap;
+                if (!snap.open(File + "." + suffix)) {
+                    cerr << "Error in opening the file: " << File << "." << suffix << "!\n\a";
+                    R.rc = 1;
+                    break;
                 }
-                off += n;
+                const Header &data = snap.header();
+                long pos_off = 0, pos_bytes = 0;
+                vector<float> mass[6];
+                if (!snap.locate_block("POS ", pos_off, pos_bytes) || (p.hydro && !snap.read_masses(mass))) {
+                    cerr << "slicer_amd: cannot read POS / MASS of " << snap.path() << endl;
+                    R.rc = 1;
+                    break;
+                }
+                slicer_file_desc f{};
+                for (int t = 0; t < 6; t++) {
+                    f.npart[t] = data.npart[t];
+                    f.massarr[t] = data.massarr[t];
+                }
+                f.boxsize = data.boxsize;
+                f.sgn[0] = random.sgnX[isnap];
+                f.sgn[1] = random.sgnY[isnap];
+                f.sgn[2] = random.sgnZ[isnap];
+                f.face = random.face[isnap];
+                f.center[0] = random.x0[isnap];
+                f.center[1] = random.y0[isnap];
+                f.center[2] = random.z0[isnap];
+                f.rcase = rcase;
+                if (slicer_file_begin(hr, &f) != SLICER_OK)
+                    return failed("file_begin");
+                size_t off = 0;
+                for (int t = 0; t < 6 && R.rc == 0; t++) {
+                    const size_t n = data.npart[t] > 0 ? (size_t)data.npart[t] : 0;
+                    if (n) {
+                        const float *m = (p.hydro && data.massarr[t] == 0 && !mass[t].empty()) ? mass[t].data() : nullptr;
+                        Span span{&snap, pos_off + (long)(12 * off), m};
+                        if (slicer_deposit_stream(hr, t, n, m != nullptr, fill_from_file, &span) != SLICER_OK)
+                            return failed("deposit");
+                    }
+                    off += n;
+                }
+                if (R.rc == 0 && slicer_file_end(hr) != SLICER_OK)
+                    return failed("file_end");
             }
-            if (rc_all == 0 && slicer_file_end(h) != SLICER_OK) {
-                cerr << "slicer_amd: " << slicer_last_error(h) << endl;
-                rc_all = 1;
+            // slicer-v2.cpp:214-217: the sum over ranks onto the root, here over RCCL on the accumulators.  Every
+            // rank takes part even after a local failure would be wrong: failures abort the run below, like MPI_Abort.
+            if (R.rc == 0 && nranks > 1 && R.comm && rccl.plane_reduce(hr, R.comm, 0, 0) != SLICER_OK) {
+                cerr << "slicer_amd (device " << R.device << "): rank sum: " << rccl.last_error() << endl;
+                R.rc = 1;
             }
+        };
+        {
+            vector<std::thread> threads;
+            for (int r = 1; r < nranks; r++)
+                threads.emplace_back(run_rank, r);
+            run_rank(0);
+            for (auto &t : threads)
+                t.join();
+            for (auto &R : ranks)
+                rc_all |= R.rc;
+            if (rc_all == 0 && nranks > 1 && reduce_mode == "host")
+                rc_all = host_plane_reduce(ranks, p.npix, (int)todo.size());
         }
         if (rc_all)
             break;
@@ -343,6 +527,10 @@ int main(int argc, char **argv)
         }
         isnap = iend;
     }
-    slicer_destroy(h);
+    for (auto &R : ranks) {
+        if (R.comm)
+            rccl.destroy(R.comm);
+        slicer_destroy(R.h);
+    }
     return rc_all;
 }

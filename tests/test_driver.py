@@ -163,3 +163,42 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
         for f in os.listdir(out):
             if f.endswith(".fits"):
                 assert open(os.path.join(out, f), "rb").read() == open(os.path.join(out, f + ".multi"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partinplanes", [0, 1])
+def test_two_rank_driver_equals_one_rank_bitwise_with_fixed64(tmp_path, partinplanes):
+    """slicer-v2.cpp:162-175 + 214-217 in the driver: `--devices 0,0` runs two ranks (two handles, one host thread each;
+    here on the same GPU, so the sum goes through host memory with --reduce host -- the RCCL clique needs distinct
+    GPUs), each depositing its contiguous range of sub-files; the partial FIXED64 accumulators are summed as integers
+    onto rank 0, which writes the planes.  Every FITS file must be byte-identical to the one-rank run.  With
+    partinplanes the second sub-file range holds species the first lacks in no case here, but the per-type maps go
+    through the same rank-invariant protocol."""
+    ini, files, out = make_cone(tmp_path, partinplanes=partinplanes)
+    assert run([ini, "--accum", "fixed64"]).returncode == 0
+    one = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out)) if f.endswith(".fits")}
+    assert len(one) >= 20
+    for f in one:
+        os.remove(os.path.join(out, f))
+    r = run([ini, "--accum", "fixed64", "--devices", "0,0", "--reduce", "host"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out)) if f.endswith(".fits")}
+    assert two.keys() == one.keys()
+    for f in one:
+        assert one[f] == two[f], f
+    # f32 accumulators: the two-rank sum differs from the one-rank one only by f32 reordering
+    for f in two:
+        os.remove(os.path.join(out, f))
+    assert run([ini, "--devices", "0,0", "--reduce", "host"]).returncode == 0
+    for f in one:
+        a = np.frombuffer(open(os.path.join(out, f), "rb").read()[2880:2880 + 4 * 1024], ">f4").astype(np.float64)
+        b = np.frombuffer(one[f][2880:2880 + 4 * 1024], ">f4").astype(np.float64)
+        assert np.allclose(a, b, rtol=3e-6, atol=2.0 ** -29)
+
+
+def test_driver_device_lists(tmp_path):
+    ini, _, _ = make_cone(tmp_path)
+    assert run([ini, "--plan-only", "--devices", "0-1"]).returncode == 0   # planning needs no device
+    assert run([ini, "--devices", "0-1", "--reduce", "bogus"]).returncode == 2
+    r = run([ini, "--devices", "0,63"])   # no such device (or no device at all here): fails loudly, nothing written
+    assert r.returncode == 1 and "slicer_amd" in r.stderr
