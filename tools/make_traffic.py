@@ -8,8 +8,11 @@ import re
 import sys
 
 summary, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
-names = {"k_project_bin": "project_bin", "k_bin_scatter": "bin_scatter", "k_tile_deposit": "tile_deposit",
-         "k_scan_blocks": "bin_scan", "k_finalize_tsc": "finalize_tsc", "k_direct": "direct_deposit"}
+names = {"k_project_bin_fast": "project_bin", "k_project_bin_general": "project_bin_general", "k_bin_scatter": "bin_scatter",
+         "k_tile_deposit": "tile_deposit", "k_scan_blocks": "bin_scan", "k_finalize_tsc": "finalize_tsc",
+         "k_direct": "direct_deposit"}
+# launches of each kernel per bench step (8 sub-files per snapshot, one tile-deposit flush per snapshot)
+per_step = {"project_bin": 8, "bin_scan": 8, "bin_scatter": 8, "tile_deposit": 1}
 cur, vals = None, {}
 for line in open(summary):
     if not line.startswith(" "):
@@ -27,5 +30,13 @@ for k, short in names.items():
     res[short] = {"workload": workload, "fetch_size_kib": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"],
                   "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
                   "tcc_ea0_atomic": v.get("TCC_EA0_ATOMIC_sum")}
+if all(k in res for k in per_step):
+    total = sum(per_step[k] * res[k]["hbm_bytes_per_launch"] for k in per_step)
+    n_in, npix, planes = 8 * (1 << 24), 4096, 4
+    alg = 12.0 * n_in + 4.0 * npix * npix * planes
+    res["whole_step"] = {"workload": workload, "hbm_bytes": total, "algorithmic_bytes": alg, "ratio": total / alg,
+                         "launches_per_step": per_step,
+                         "note": "sum over the step's launches of (2 * FETCH_SIZE + WRITE_SIZE); algorithmic = 12 B per "
+                                 "input particle + 4 B per map pixel (SURVEY S8d); the accumulator memsets are not counted"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
