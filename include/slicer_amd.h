@@ -59,7 +59,12 @@ extern "C" {
 /* accumulator of the TSC maps (NGP always uses exact u32 counts when the mass is constant) */
 #define SLICER_ACC_F32 0     /* f32 atomics: fastest, order-dependent in the last bits            */
 #define SLICER_ACC_F64 1     /* f64 atomics, rounded to f32 once at finalize                       */
-#define SLICER_ACC_FIXED64 2 /* 64-bit fixed point: order-independent => bitwise reproducible sums */
+#define SLICER_ACC_FIXED64 2 /* 64-bit fixed point: order-independent => bitwise reproducible sums (also across ranks).
+                              * ABSOLUTE accuracy: every contribution is rounded to 2^-fixed_frac_bits (default 2^-40) of
+                              * the mass scale 2^ceil(log2 m) -- or of 2^10 (MAX_M) with per-particle masses -- so a pixel
+                              * that holds nothing but a vanishing TSC weight (<< 1e-6 m) loses RELATIVE precision; pixels
+                              * holding >= 1e-3 m agree with the f64 accumulator to < 1 f32 ulp.  F32 / F64 keep the
+                              * relative per-pixel bound.  A cell overflows at 2^(64 - fixed_frac_bits) mass scales. */
 
 /* deposit algorithm */
 #define SLICER_ALGO_AUTO 0
