@@ -454,6 +454,115 @@ __device__ __forceinline__ float ngp_seq_sum(unsigned k, float m)
     return s;
 }
 
+// ---- heavy bins: wave-level pre-reduction before the LDS atomic ---------------------------------------------------
+// A bin that k_build_items split into parts holds a halo core: many records in a few pixels.  64 lanes adding to the
+// same LDS cell serialise (the 9 ds_add of a wave cost ~64x their usual LDS time), so the parts of such bins first ask
+// whether every active lane of the wave targets the same cell; if so the nine contributions are summed across the wave
+// (xor butterfly) and one lane issues the nine atomics.  Sums are reordered (allowed in the F32 / F64 modes, exact in
+// FIXED64: integers); waves that straddle several cells fall back to per-lane atomics.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += (unsigned long long)__shfl_xor((long long)v, off);
+    return v;
+}
+
+template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+__device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, const PassParams &P,
+                                                       typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
+                                                       unsigned nparts, int x0, int y0, int W)
+{
+    using lds_t = typename AccT<ACC>::lds;
+    const int tid = threadIdx.x;
+    const int nn = P.nn;
+    for (int c = 0; c < L.n; c++) {
+        const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
+        const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
+        const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+        const float2 *__restrict__ sxy = L.sxy[c];
+        const float *__restrict__ sm = L.sm[c];
+        // every lane of the workgroup runs every iteration (no divergent exit: the butterfly needs all lanes)
+        for (unsigned i0 = start; i0 < end; i0 += kTileBlock) {
+            const unsigned i = i0 + tid;
+            const bool act = i < end;
+            const float2 r = act ? sxy[i] : make_float2(0.f, 0.f);
+            float m = L.mconst[c], sq = L.sm_const[c];
+            if (HAS_MASS) {
+                m = act ? cap_mass(sm[i]) : 0.f;
+                sq = __fsqrt_rn(m);
+            }
+            const int gx = grid_index<POW2>(r.x, P), gy = grid_index<POW2>(r.y, P);
+            const int cell = act ? (gy - y0) * W + (gx - x0) : -1;  // cell (gx - 1, gy - 1) of the halo'd tile
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull)
+                continue;
+            const int lead = (int)__builtin_ctzll(am);
+            const int cell0 = __shfl(cell, lead);
+            const bool uniform = __ballot(act && cell != cell0) == 0ull;
+            if (MAS == kNGP) {
+                if (uniform) {
+                    if ((int)lane_id() == lead) {
+                        lds_t *cc = tile + cell0 + W + 1;
+                        if (ACC == kCountU32)
+                            atomicAdd(reinterpret_cast<unsigned *>(cc), (unsigned)__popcll(am));
+                    }
+                    if (ACC != kCountU32) {
+                        const double tot = wave_sum(act ? (double)m : 0.0);
+                        if ((int)lane_id() == lead)
+                            atomicAdd(reinterpret_cast<double *>(tile + cell0 + W + 1), tot);
+                    }
+                } else if (act) {
+                    lds_t *cc = tile + cell + W + 1;
+                    if (ACC == kCountU32)
+                        atomicAdd(reinterpret_cast<unsigned *>(cc), 1u);
+                    else
+                        atomicAdd(reinterpret_cast<double *>(cc), (double)m);
+                }
+                continue;
+            }
+            float wx[3], wy[3];
+            tsc_axis<POW2>(r.x, gx, P, wx);
+            tsc_axis<POW2>(r.y, gy, P, wy);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                wx[a] = sq * wx[a];
+                wy[a] = sq * wy[a];
+            }
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    // map-edge tests as in the CHECK variant (heavy border tiles are rare enough not to specialise)
+                    const int px = gx + a - 1, py = gy + b - 1;
+                    const bool in = act && px >= 0 && px < nn && py >= 0 && py < nn;
+                    const float cf = wx[a] * wy[b];
+                    if (uniform) {  // wave-uniform branch
+                        if (ACC == kFixed64) {
+                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, P.fixed_scale) : 0ull);
+                            if ((int)lane_id() == lead && tot)
+                                atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
+                        } else {
+                            const double tot = wave_sum(in ? (double)cf : 0.0);
+                            if ((int)lane_id() == lead && tot != 0.0)
+                                atomicAdd(reinterpret_cast<double *>(tile + cell0 + b * W + a), tot);
+                        }
+                    } else if (in) {
+                        lds_add<ACC>(tile + cell + b * W + a, cf, P);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
                                                              TileItems I, NgpFold F)
@@ -491,7 +600,9 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 
     // the halo [x0 - 1, x0 + W - 2] x [y0 - 1, y0 + H - 2] inside the map: no cell of this tile needs the edge test
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
-    if (MAS == kNGP || interior)
+    if (nparts > 1)
+        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W);
+    else if (MAS == kNGP || interior)
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W);
     else
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W);

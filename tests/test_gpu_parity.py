@@ -425,11 +425,19 @@ def test_random_configurations_binned_path(S, seed):
     lds = [rcase + float(e) for e in edges[0::2]]
     ld2s = [rcase + float(e) for e in edges[1::2]]
     fov = float(rng.uniform(0.05, 0.9)) / max(ld2s)          # <= the box at the far side of the last slab
+    centre = rng.random(3)
+    if rng.random() < 0.6:  # binary32 centres, as the reference draws them: these runs qualify for the fast K1 kernel
+        centre = centre.astype(np.float32)
     rnd = dict(sgn=tuple(int(v) for v in rng.choice([-1, 1], 3)), face=int(rng.integers(1, 7)),
-               center=tuple(float(v) for v in rng.random(3)), rcase=rcase)
+               center=tuple(float(v) for v in centre), rcase=rcase)
     n = int(rng.integers(70000, 400000))
     cut = int(rng.integers(1, n))
     pos = synth.positions(int(rng.integers(0, 1 << 20)), n, BOX, clustered=bool(rng.random() < 0.3))
+    # raw coordinates on and around the edges of the transform's fast domain
+    special = np.array([0.0, -0.0, BOX, 1e-30, 1e-38, np.nextafter(np.float32(BOX), np.float32(0)), 0.5 * BOX],
+                       np.float32)
+    k = int(rng.integers(0, 200))
+    pos[rng.integers(0, n, k), rng.integers(0, 3, k)] = special[rng.integers(0, len(special), k)]
     m = float(rng.uniform(0.001, 50.0))
     files = [dict(npart=[0, cut, 0, 0, 0, 0], massarr=[0, m, 0, 0, 0, 0], boxsize=BOX, pos=pos[:cut]),
              dict(npart=[0, n - cut, 0, 0, 0, 0], massarr=[0, m, 0, 0, 0, 0], boxsize=BOX, pos=pos[cut:])]

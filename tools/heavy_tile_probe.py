@@ -14,7 +14,7 @@ n = 1 << 24
 BOX = 1000.0
 rng = np.random.default_rng(0)
 S = slicer_amd.Slicer(0, max_chunk=n)
-for frac, nblob, sig in ((0.0, 1, 1.0), (0.5, 4096, 4.0), (0.5, 64, 0.2), (0.5, 4, 0.05), (0.9, 1, 0.02)):
+for frac, nblob, sig in ((0.0, 1, 1.0), (0.5, 4096, 4.0), (0.5, 64, 0.2), (0.5, 4, 0.05), (0.9, 1, 0.02), (0.9, 1, 0.002)):
     pos = synth.positions(0, n, BOX)
     k = int(frac * n)
     if k:
