@@ -317,6 +317,17 @@ template <int ACC> struct AccT { using type = float; using lds = double; };
 template <> struct AccT<kF64> { using type = double; using lds = double; };
 template <> struct AccT<kFixed64> { using type = unsigned long long; using lds = unsigned long long; };
 template <> struct AccT<kCountU32> { using type = unsigned; using lds = unsigned; };
+template <> struct AccT<kF32I> { using type = float; using lds = unsigned long long; };
+template <> struct AccT<kF64I> { using type = double; using lds = unsigned long long; };
+template <int ACC> constexpr bool kIntCells = ACC == kF32I || ACC == kF64I;
+
+// Integer tile cells of the F32 / F64 modes.  A contribution c is exact in units of 2^-49 of the mass scale iff
+// c * tile_scale is an integer -- true for every c >= tile_cmin = 2^-25 scales (24-bit mantissa), i.e. for all but the
+// ~0.1 % of contributions that are vanishing TSC weights.  Those are not rounded into the tile (a pixel holding nothing
+// else must come out exact: T-TSC with k = 1) but added straight to the global map with a float atomic.  The kernel
+// tests one number per record -- the smallest of its nine products -- and notes the rare records that fail in an LDS
+// list, treated after the loop (slow_record); the loop itself stays branch-free.
+constexpr unsigned kSlowCap = 1024;  // noted records per work item (<= 16384 records: 1 % are ~160)
 
 template <int ACC>
 __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, const PassParams &P)
@@ -325,6 +336,40 @@ __device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, 
         atomicAdd(reinterpret_cast<double *>(cell), (double)c);  // ds_add_f64
     else if (ACC == kFixed64)
         atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, P.fixed_scale));  // ds_add_u64
+    else if (kIntCells<ACC>)
+        atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, P.tile_scale));
+}
+
+// One record of an integer-cell tile with the representability test per contribution: exact ones into the tile, the
+// others straight to the global accumulator map (gmap, acc_t = float or double).
+template <int ACC, bool POW2>
+__device__ __forceinline__ void slow_record(float xs, float ys, float sq, const PassParams &P,
+                                            typename AccT<ACC>::lds *tile, typename AccT<ACC>::type *gmap, int x0, int y0,
+                                            int W)
+{
+    using acc_t = typename AccT<ACC>::type;
+    const int nn = P.nn;
+    const int gx = grid_index<POW2>(xs, P), gy = grid_index<POW2>(ys, P);
+    float wx[3], wy[3];
+    tsc_axis<POW2>(xs, gx, P, wx);
+    tsc_axis<POW2>(ys, gy, P, wy);
+    for (int a = 0; a < 3; a++) {
+        wx[a] = sq * wx[a];
+        wy[a] = sq * wy[a];
+    }
+    for (int b = 0; b < 3; b++)
+        for (int a = 0; a < 3; a++) {
+            const int px = gx + a - 1, py = gy + b - 1;
+            if (px < 0 || px >= nn || py < 0 || py >= nn)
+                continue;
+            const float c = wx[a] * wy[b];
+            const double t = (double)c * P.tile_scale;
+            if (t == rint(t))
+                atomicAdd(reinterpret_cast<unsigned long long *>(tile + (gy - y0 + b) * W + (gx - x0 + a)),
+                          (unsigned long long)t);
+            else
+                atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)c);
+        }
 }
 
 // Work items of the tile kernel: a (plane, tile) bin with many records (a halo core can put 10^5..10^7
@@ -369,7 +414,8 @@ constexpr int kTileBlock = 1024;
 template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK>
 __device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
                                                 typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
-                                                unsigned nparts, int x0, int y0, int W)
+                                                unsigned nparts, int x0, int y0, int W, unsigned *s_nslow,
+                                                uint2 *s_slow, typename AccT<ACC>::type *gmap)
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
@@ -425,6 +471,18 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
                         wx[a] = sq * wx[a];
                         wy[a] = sq * wy[a];
                     }
+                    if (kIntCells<ACC>) {
+                        // smallest of the nine products (weights are >= 0; the centre cell holds the largest)
+                        const float cmin = fminf(wx[0], wx[2]) * fminf(wy[0], wy[2]);
+                        if (cmin < P.tile_cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
+                            const unsigned k = atomicAdd(s_nslow, 1u);
+                            if (k < kSlowCap)
+                                s_slow[k] = make_uint2((unsigned)c, i);
+                            else
+                                slow_record<ACC, POW2>(xs, ys, sq, P, tile, gmap, x0, y0, W);
+                            continue;
+                        }
+                    }
                     lds_t *cell0 = tile + (gy - y0) * W + (gx - x0);  // cell (gx - 1, gy - 1)
 #pragma unroll
                     for (int b = 0; b < 3; b++) {
@@ -478,7 +536,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, const PassParams &P,
                                                        typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
-                                                       unsigned nparts, int x0, int y0, int W)
+                                                       unsigned nparts, int x0, int y0, int W,
+                                                       typename AccT<ACC>::type *gmap)
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
@@ -542,10 +601,21 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
                 for (int a = 0; a < 3; a++) {
                     // map-edge tests as in the CHECK variant (heavy border tiles are rare enough not to specialise)
                     const int px = gx + a - 1, py = gy + b - 1;
-                    const bool in = act && px >= 0 && px < nn && py >= 0 && py < nn;
+                    bool in = act && px >= 0 && px < nn && py >= 0 && py < nn;
                     const float cf = wx[a] * wy[b];
+                    if (kIntCells<ACC>) {  // contributions that are no multiple of the tile's quantum bypass the tile
+                        const double t = (double)cf * P.tile_scale;
+                        if (in && t != rint(t)) {
+                            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (typename AccT<ACC>::type)cf);
+                            in = false;
+                        }
+                    }
                     if (uniform) {  // wave-uniform branch
-                        if (ACC == kFixed64) {
+                        if (kIntCells<ACC>) {
+                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, P.tile_scale) : 0ull);
+                            if ((int)lane_id() == lead && tot)
+                                atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
+                        } else if (ACC == kFixed64) {
                             const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, P.fixed_scale) : 0ull);
                             if ((int)lane_id() == lead && tot)
                                 atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
@@ -594,19 +664,39 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     const int tid = threadIdx.x;
     const int nn = P.nn;
 
+    // behind the tile (no static __shared__ in this kernel: it would sit in front of the dynamic array and leave the
+    // 8-byte cells 4-byte aligned -- misaligned 64-bit LDS atomics fault): a counter, then the list of noted records
+    unsigned &s_nslow = *reinterpret_cast<unsigned *>(tile + cells);
+    uint2 *s_slow = reinterpret_cast<uint2 *>(tile + cells) + 1;  // [kSlowCap] {chunk, record}: integer-cell modes only
+    acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
     for (int i = tid; i < cells; i += kTileBlock)
         tile[i] = (lds_t)0;
+    if (tid == 0)
+        s_nslow = 0;
     __syncthreads();
 
     // the halo [x0 - 1, x0 + W - 2] x [y0 - 1, y0 + H - 2] inside the map: no cell of this tile needs the edge test
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
-    if (nparts > 1)
-        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W);
+    // pre-reduction only for bins far beyond a tile's usual load (>= 8 parts = 131072 records: a halo core); a bin that
+    // is merely split in two or three is faster through the plain loop (--clustered: 810 us with, 700 us without)
+    if (nparts >= 8)
+        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap);
     else if (MAS == kNGP || interior)
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W);
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap);
     else
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W);
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap);
     __syncthreads();
+    if (kIntCells<ACC>) {
+        // the records noted in the loop: those of their contributions that are exact multiples of the quantum go into
+        // the tile like all others, the vanishing ones straight to the global map
+        const unsigned ns = s_nslow < kSlowCap ? s_nslow : kSlowCap;
+        for (unsigned e = tid; e < ns; e += kTileBlock) {
+            const uint2 w = s_slow[e];
+            const float2 r = L.sxy[w.x][w.y];
+            slow_record<ACC, POW2>(r.x, r.y, L.sm_const[w.x], P, tile, gmap, x0, y0, W);
+        }
+        __syncthreads();
+    }
 
     if (ACC == kCountU32 && F.on && nparts == 1) {
         // NGP fold in place: this workgroup is the only one that touches these pixels in this launch (NGP records hit
@@ -625,7 +715,6 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         return;
     }
     // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
-    acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
     for (int i = tid; i < cells; i += kTileBlock) {
         const lds_t v = tile[i];
         if (v == (lds_t)0)
@@ -634,7 +723,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         const int px = x0 - 1 + i % W;
         if (px < 0 || px >= nn || py < 0 || py >= nn)
             continue;
-        atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)v);
+        if (kIntCells<ACC>)  // exact tile sum -> one rounding to the accumulator type
+            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)((double)v * P.tile_inv_scale));
+        else
+            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)v);
     }
 }
 
@@ -721,7 +813,8 @@ hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, i
 size_t tile_lds_bytes(const BinGeom &G, int acc)
 {
     const size_t elem = acc == kCountU32 ? 4 : 8;
-    return elem * (size_t)((1 << G.tw_log2) + 2) * (size_t)((1 << G.th_log2) + 2);
+    const size_t cells = (size_t)((1 << G.tw_log2) + 2) * (size_t)((1 << G.th_log2) + 2);
+    return ((elem * cells + 7) & ~(size_t)7) + 8 + ((acc == kF32I || acc == kF64I) ? kSlowCap * sizeof(uint2) : 0);
 }
 
 template <int MAS, int ACC>
@@ -780,6 +873,18 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
             return e;
         }
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
+    }
+    // constant-mass TSC in the F32 / F64 modes: integer tile cells (SLICER_K4_INT=0 keeps the f64 cells)
+    static const bool int_cells = !(getenv("SLICER_K4_INT") && atoi(getenv("SLICER_K4_INT")) == 0);
+    if (int_cells && !cfg.has_mass && (cfg.acc == kF32 || cfg.acc == kF64)) {
+        bool same_mass = true;  // one quantum per launch: all pending chunks carry the same constant mass
+        for (int c = 1; c < L.n; c++)
+            same_mass = same_mass && L.mconst[c] == L.mconst[0];
+        if (same_mass && L.mconst[0] == P.mconst) {
+            if (cfg.acc == kF32)
+                return launch_k4<kTSC, kF32I>(pow2, false, P, G, L, T, I, F, max_items, s);
+            return launch_k4<kTSC, kF64I>(pow2, false, P, G, L, T, I, F, max_items, s);
+        }
     }
     switch (cfg.acc) {
     case kF32: return launch_k4<kTSC, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);

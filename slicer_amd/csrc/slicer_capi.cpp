@@ -305,6 +305,14 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
     P.sm_const = sqrtf(P.mconst);       // glibc sqrtf is correctly rounded, as std::sqrt(float)
     int e = d.want_type_maps ? h->fixed_exp[type] : h->fixed_exp_shared;
     P.fixed_scale = std::ldexp(1.0, e);
+    {
+        int le = 10;  // MAX_M = 1e3 < 2^10
+        if (P.mconst > 0 && std::isfinite(P.mconst))
+            le = std::ilogb(P.mconst) + 1;
+        P.tile_scale = std::ldexp(1.0, 49 - le);
+        P.tile_inv_scale = std::ldexp(1.0, le - 49);
+        P.tile_cmin = std::ldexp(1.0f, le - 25);
+    }
     (void)has_mass;
 }
 

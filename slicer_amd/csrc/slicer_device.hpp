@@ -56,6 +56,10 @@ struct PassParams {
     float sm_const;  // sqrtf(mconst), IEEE correctly rounded
     // --- fixed-point accumulation ---
     double fixed_scale;  // 2^k
+    // --- integer tile cells of the F32 / F64 modes (k_tile_deposit) ---
+    double tile_scale;      // 2^(49 - le), le = ilogb(m) + 1: a contribution c adds rint(c * tile_scale) to its cell
+    double tile_inv_scale;  // 2^(le - 49)
+    float tile_cmin;        // 2^(le - 25): every contribution >= this is an exact multiple of 2^(le - 49)
 };
 
 // (float)(sgn * ((double)r / box))      gadget2io.cpp:204-206

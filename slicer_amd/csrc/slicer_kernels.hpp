@@ -8,7 +8,10 @@
 namespace slicer {
 
 enum Mas { kTSC = 0, kNGP = 1 };
-enum Acc { kF32 = 0, kF64 = 1, kFixed64 = 2, kCountU32 = 3 };  // kCountU32: NGP constant-mass counts
+enum Acc { kF32 = 0, kF64 = 1, kFixed64 = 2, kCountU32 = 3,  // kCountU32: NGP constant-mass counts
+           // tile kernel only: f32 / f64 global accumulators behind INTEGER tile cells in LDS (exact tile sums at
+           // 2^-49 of the mass scale; ds_add_u64 runs at twice the rate of ds_add_f64)
+           kF32I = 4, kF64I = 5 };
 
 // Where the deposits of the current (file, type) go.
 struct Targets {
