@@ -9,10 +9,14 @@ Workload (BASELINE config[2], the configuration the metric is quoted on; it fits
   centre (.3,.6,.1)).  One step = one snapshot -> its 4 plane maps: plane_begin (zero) + 8 sub-file
   deposits + finalize.  Steps cycle through the resident snapshots.
 N > 1 (one process per GPU; `python bench.py --gpus N` starts the N ranks itself when no launcher did):
-  --shard files (default, "scaling": "strong"): the SAME job, split the way the reference splits it -- every
-      snapshot's sub-files in contiguous ranges over the ranks (slicer-v2.cpp:162-175) -- followed by the per-plane
-      sum to rank 0 (slicer-v2.cpp:214-217) over RCCL/xGMI, in the accumulator's own type; the sum of step i
-      overlaps the deposits of step i+1 (two handles, RCCL on its own stream).
+  --shard steps (default, "scaling": "strong"): the SAME job and the same steps; step i (one snapshot -> its 4 plane
+      maps) is built by rank i % N alone, and every finished map then travels to rank 0 point to point over RCCL/xGMI
+      (rank 0 ends up with every map, as in slicer-v2.cpp:214-222), overlapped with the steps that follow.  Snapshots
+      and lens planes shard without partial sums, so nothing needs adding up -- and at 5e10 particles/s a per-snapshot
+      sum of 4 x 64 MiB over xGMI costs more than the snapshot.
+  --shard files ("strong"): split the way the reference splits it -- every snapshot's sub-files in contiguous ranges
+      over the ranks (slicer-v2.cpp:162-175) -- followed by the per-plane SUM to rank 0 (slicer-v2.cpp:214-217) over
+      RCCL/xGMI, in the accumulator's own type; the sum of step i overlaps the deposits of step i+1.
   --shard snapshots ("weak"): every rank owns its own boxes, no data-path collective (SURVEY S8e level 2).
 value = deposits of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON line.
 """
@@ -58,8 +62,8 @@ def parse():
     ap.add_argument("--clustered", action="store_true")
     ap.add_argument("--hydro", action="store_true",
                     help="per-particle masses (type 0, massarr = 0: densitymaps.cpp:358-372) instead of one mass per type")
-    ap.add_argument("--shard", default="auto", choices=["auto", "snapshots", "files"],
-                    help="auto: files (strong scaling + per-plane RCCL reduce) when N > 1")
+    ap.add_argument("--shard", default="auto", choices=["auto", "snapshots", "files", "steps"],
+                    help="auto: steps (strong scaling, whole steps per rank, finished maps sent to rank 0) when N > 1")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
@@ -201,7 +205,7 @@ def main():
         if world == 1:
             raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is 1: refusing to report a {a.gpus}-GPU number from one rank")
         a.gpus = world
-    shard = a.shard if a.shard != "auto" else ("files" if world > 1 else "snapshots")
+    shard = a.shard if a.shard != "auto" else ("steps" if world > 1 else "snapshots")
 
     cpu, ref_maps = None, None
     want_parity = a.parity == "on" or (a.parity == "auto" and a.mas == "tsc" and a.side ** 3 // a.files >= a.cpu_particles
@@ -255,7 +259,8 @@ def main():
     ptype = 0 if a.hydro else 1
 
     reduce_steps = shard == "files" and use_dist
-    overlap = reduce_steps and not a.no_overlap
+    gather_steps = shard == "steps" and use_dist
+    overlap = (reduce_steps or gather_steps) and not a.no_overlap
     # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and workspace
     # and works on its own stream; RCCL runs on torch.distributed's communication stream.
     n_handles = 2 if overlap else 1
@@ -269,6 +274,9 @@ def main():
     my_snaps = list(range(a.snapshots))
     if shard == "snapshots":
         seed0 = SEED + 1000 * rank          # every rank owns different boxes
+        my_files = list(range(files))
+    elif shard == "steps":
+        seed0 = SEED                        # same boxes everywhere; a rank builds whole steps, all sub-files
         my_files = list(range(files))
     else:
         seed0 = SEED                        # same boxes everywhere, sub-files split as slicer-v2.cpp:162-175
@@ -290,34 +298,69 @@ def main():
             masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
     torch.cuda.synchronize()
 
-    pending = [None] * n_handles  # async rank-sum works of the handle's previous step
+    pending = [None] * n_handles  # async rank-sum / send works of the handle's previous step
+    npix2 = a.npix * a.npix
+    G = None
+    if gather_steps:
+        G = parallel.StepGather(dist, torch, world, rank, len(lds), npix2, torch.float32, "cuda", root=0, depth=2)
+    own_count = [0]
 
     def settle(k):
-        """Step k's rank sum has to be complete before its accumulators become f32 maps (and are reused)."""
+        """Step k's rank sum has to be complete before its accumulators become f32 maps (and are reused); sends of
+        the handle's previous step have to be complete before its maps are zeroed again."""
         if pending[k] is not None:
             with torch.cuda.stream(streams[k]):
                 for w in pending[k]:
                     w.wait()
-                handles[k].plane_finalize()
+                if reduce_steps:
+                    handles[k].plane_finalize()
             pending[k] = None
 
+    def deposit(S, s):
+        S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
+        for j, ff in enumerate(my_files):
+            if a.hydro:
+                S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                             RND["center"], RND["rcase"])
+                S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
+            else:
+                S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                             RND["center"], RND["rcase"])
+                S.deposit_device(1, pos[s][j].data_ptr(), per_file)
+            S.file_end()
+
+    def local_step(i, k=0):
+        """One snapshot -> its finished plane maps on this rank, no communication."""
+        with torch.cuda.stream(streams[k]):
+            deposit(handles[k], i % len(my_snaps))
+            handles[k].plane_finalize()
+
     def step(i):
+        s = i % len(my_snaps)
+        if gather_steps:
+            if G.owner(i) == rank:  # this rank builds the whole step; the root gets the maps
+                k = own_count[0] % n_handles
+                own_count[0] += 1
+                settle(k)
+                with torch.cuda.stream(streams[k]):
+                    deposit(handles[k], s)
+                    handles[k].plane_finalize()
+                    if rank != 0:
+                        maps = [parallel.device_tensor(torch, handles[k].plane_device_maps(p)[0], npix2)
+                                for p in range(len(lds))]
+                        pending[k] = G.send(i, maps)
+                        if not overlap:
+                            settle(k)
+            elif rank == 0:
+                G.expect(i)  # (waits for the ring slot's previous occupant first)
+                if not overlap:
+                    G.complete(i)
+            return
         k = i % n_handles
         S = handles[k]
         settle(k)
-        s = i % len(my_snaps)
         with torch.cuda.stream(streams[k]):
-            S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
-            for j, ff in enumerate(my_files):
-                if a.hydro:
-                    S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                                 RND["center"], RND["rcase"])
-                    S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
-                else:
-                    S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                                 RND["center"], RND["rcase"])
-                    S.deposit_device(1, pos[s][j].data_ptr(), per_file)
-                S.file_end()
+            deposit(S, s)
             if reduce_steps:
                 # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL over xGMI, on the accumulators
                 # (f32 / f64 / fixed point), converted to f32 maps once, after the sum
@@ -331,14 +374,20 @@ def main():
     def drain():
         for k in range(n_handles):
             settle(k)
+        if G is not None:
+            G.finish()
 
     # deposits per step (identical for a given snapshot every time it is processed); with --shard files the counters
     # on rank 0 are the rank sums (reduced with the maps)
     dep_per_snap = []
     for s in range(len(my_snaps)):
-        step(s)
-        drain()
-        dep_per_snap.append(sum(int(_counts(handles[s % n_handles], p)[ptype]) for p in range(len(lds))))
+        if gather_steps:
+            local_step(s)  # every rank learns the counts of every snapshot (outside the timed region)
+        else:
+            step(s)
+            drain()
+        dep_per_snap.append(sum(int(_counts(handles[0 if gather_steps else s % n_handles], p)[ptype])
+                                for p in range(len(lds))))
     algo_mask = S0.algo_mask()
 
     for i in range(a.warmup):
@@ -360,7 +409,12 @@ def main():
 
     my_dep = sum(dep_per_snap[i % len(my_snaps)] for i in range(a.steps))
     my_in = a.steps * per_file * len(my_files)
-    if use_dist:
+    if gather_steps:  # the K steps are the job, whichever rank built them: my_dep / my_in already are the totals
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot_dep, tot_in = float(my_dep), float(my_in)
+    elif use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -375,7 +429,11 @@ def main():
     S0.profile_reset()
     S0.profile_enable(True)
     for i in range(max(1, a.profile_steps) * n_handles):
-        step(i)
+        if gather_steps:
+            if i % n_handles == 0:
+                local_step(i)
+        else:
+            step(i)
     drain()
     torch.cuda.synchronize()
     S0.profile_enable(False)
@@ -385,6 +443,8 @@ def main():
     # algorithmic bytes per launch of the dominant kernel (DESIGN.md "Algorithmic bytes")
     # (the profiled handle ran max(1, profile_steps) steps; every project_bin launch streams one sub-file)
     dep_per_step_rank = (my_dep / max(a.steps, 1)) * (len(my_files) / files if reduce_steps else 1.0)
+    if gather_steps:
+        dep_per_step_rank = my_dep / max(a.steps, 1)
     if dom_name in ("direct_deposit", "project_bin"):
         alg_bytes = 12.0 * per_file
     elif dom_name in ("tile_deposit", "bin_scatter", "bin_sort"):
@@ -457,10 +517,12 @@ def main():
                             f"resident in HBM, {a.npix}^2 {a.mas.upper()}, {len(lds)} lens planes per pass, "
                             f"{'clustered' if a.clustered else 'uniform'}",
                 "shard": shard, "algo": a.algo, "accum": a.accum, "algo_mask": algo_mask,
-                "collective": ("per-plane sum to rank 0 in the accumulator type over RCCL, "
-                               + ("overlapped with the next step" if overlap else "not overlapped")) if reduce_steps else None,
-                "particles_in_per_step": per_file * (files if shard == "files" else len(my_files)),
-                "particles_deposited_per_step": tot_dep / max(a.steps, 1) / (1 if shard == "files" else world),
+                "collective": (("per-plane sum to rank 0 in the accumulator type over RCCL, " if reduce_steps else
+                                "finished plane maps sent to rank 0 point to point over RCCL, ")
+                               + ("overlapped with the following steps" if overlap else "not overlapped"))
+                if (reduce_steps or gather_steps) else None,
+                "particles_in_per_step": per_file * (files if shard in ("files", "steps") else len(my_files)),
+                "particles_deposited_per_step": tot_dep / max(a.steps, 1) / (1 if shard in ("files", "steps") else world),
             },
             "n_in_per_s": tot_in / dt,
             "hbm_read_roofline_frac_whole_step": 12.0 * tot_in / dt / HBM_PEAK / world,

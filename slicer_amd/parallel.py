@@ -83,3 +83,72 @@ def reduce_host_maps(dist, torch, maps, root=0):
         if dist.get_rank() == root:
             m[...] = t.numpy().reshape(m.shape)
     return maps
+
+
+class StepGather:
+    """Strong scaling by whole steps: step i (one snapshot -> its plane maps) belongs to rank i % world, which builds
+    it alone -- no partial sums exist, so nothing is reduced -- and every finished map then travels to `root` point to
+    point (torch.distributed isend / irecv = RCCL send / recv over the direct xGMI link of that pair), overlapped with
+    the steps that follow.  The root ends up with every map, as rank 0 does in slicer-v2.cpp:214-222, but each link only
+    carries the maps its own rank built (a rooted reduce would push every map through every rank).
+
+    Root side: `expect(i)` posts the receives of step i (owner != root) into a ring of `depth` slots per peer.
+    Owner side: `send(i, tensors)` posts the sends of step i and returns the works to wait on before the buffers are
+    reused.  `finish()` waits for everything still in flight.  Tensors: CPU (gloo rehearsal) or device."""
+
+    def __init__(self, dist, torch, world, rank, n_maps, numel, dtype, device, root=0, depth=2):
+        self.dist, self.world, self.rank, self.root, self.depth = dist, world, rank, root, depth
+        self.n_maps = n_maps
+        self.slots, self.inflight = {}, {}
+        if rank == root:
+            for peer in range(world):
+                if peer != root:
+                    self.slots[peer] = [[torch.empty(numel, dtype=dtype, device=device) for _ in range(n_maps)]
+                                        for _ in range(depth)]
+                    self.inflight[peer] = [None] * depth
+        self.sent = []
+
+    def owner(self, i):
+        return i % self.world
+
+    def expect(self, i):
+        """Root: post the receives of step i into its ring slot; `complete(i)` makes the slot's tensors valid."""
+        peer = self.owner(i)
+        assert self.rank == self.root and peer != self.root
+        k = (i // self.world) % self.depth
+        self._wait_slot(peer, k)  # the slot's previous occupant must have arrived (and been consumed by the caller)
+        # (tags keep gloo's matching unambiguous with several messages of one pair in flight; RCCL matches in order)
+        works = [self.dist.irecv(t, src=peer, tag=i * self.n_maps + p) for p, t in enumerate(self.slots[peer][k])]
+        self.inflight[peer][k] = works
+        return self.slots[peer][k]
+
+    def complete(self, i):
+        """Root: wait until the maps of step i have arrived; returns them (valid until the slot is reused by
+        expect(i + depth * world))."""
+        peer = self.owner(i)
+        k = (i // self.world) % self.depth
+        self._wait_slot(peer, k)
+        return self.slots[peer][k]
+
+    def _wait_slot(self, peer, k):
+        works = self.inflight[peer][k]
+        if works is not None:  # each work is waited on exactly once (a second wait on a gloo receive blocks)
+            for w in works:
+                w.wait()
+            self.inflight[peer][k] = None
+
+    def send(self, i, tensors):
+        """Owner (not the root): post the sends of step i."""
+        assert self.owner(i) == self.rank and self.rank != self.root and len(tensors) == self.n_maps
+        works = [self.dist.isend(t, dst=self.root, tag=i * self.n_maps + p) for p, t in enumerate(tensors)]
+        self.sent.append(works)
+        return works
+
+    def finish(self):
+        for works in self.sent:
+            for w in works:
+                w.wait()
+        self.sent = []
+        for peer, slots in self.inflight.items():
+            for k in range(len(slots)):
+                self._wait_slot(peer, k)

@@ -135,6 +135,66 @@ def test_two_rank_accumulator_typed_reduce_with_a_species_missing_on_one_rank():
         assert all(res[r].values()), (r, res[r])
 
 
+def _worker_steps(rank, world, port, q):
+    """StepGather (bench.py's default N > 1 layout) on CPU tensors: owners build whole steps, the root collects."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from slicer_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_maps, numel, steps = 3, 1000, 11
+    G = parallel.StepGather(dist, torch, world, rank, n_maps, numel, torch.float32, "cpu", root=0, depth=2)
+
+    def build(i):  # what the owner of step i produces
+        return [torch.full((numel,), float(100 * i + p)) for p in range(n_maps)]
+    got = {}
+    pending = []
+    for i in range(steps):
+        if G.owner(i) == rank:
+            maps = build(i)
+            if rank == 0:
+                got[i] = [m.clone() for m in maps]
+            else:
+                G.send(i, maps)
+        elif rank == 0:
+            peer_steps = [j for j in pending if G.owner(j) == G.owner(i)]
+            if len(peer_steps) >= 2:  # ring depth 2 per peer: consume the older step before its slot is reused
+                j = peer_steps[0]
+                got[j] = [t.clone() for t in G.complete(j)]
+                pending.remove(j)
+            G.expect(i)
+            pending.append(i)
+    for j in pending:
+        got[j] = [t.clone() for t in G.complete(j)]
+    G.finish()
+    dist.barrier()
+    ok = True
+    if rank == 0:
+        ok = sorted(got) == list(range(steps)) and all(
+            bool((got[i][p] == float(100 * i + p)).all()) for i in range(steps) for p in range(n_maps))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_step_gather_delivers_every_map_to_the_root(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_steps, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res.values()), res
+
+
 def test_file_partition_matches_reference_rule():
     from slicer_amd import parallel
     import oracle
