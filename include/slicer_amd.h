@@ -48,7 +48,7 @@ extern "C" {
 #define SLICER_ERR_STATE 3
 #define SLICER_ERR_HIP 4
 #define SLICER_ERR_NOMEM 5
-#define SLICER_ERR_UNSUPPORTED 6 /* e.g. snopt > 0 with several planes in one pass */
+#define SLICER_ERR_UNSUPPORTED 6 /* e.g. SLICER_ALGO_BINNED asked for a pass it cannot serve */
 #define SLICER_ERR_NO_DEVICE 7
 
 /* mass-assignment scheme: DO_NGP is a compile-time macro in the reference (densitymaps.h:22),
@@ -90,7 +90,7 @@ typedef struct {
     int32_t accum;                         /* SLICER_ACC_*  (TSC)                                */
     int32_t algo;                          /* SLICER_ALGO_*                                      */
     int32_t hydro;                         /* InputParams.hydro (data.h:35)                      */
-    int32_t snopt;                         /* InputParams.snopt (data.h:45); > 0: n_planes must be 1; draws libc rand() */
+    int32_t snopt;                         /* InputParams.snopt (data.h:45); > 0 draws libc rand(), plane-major */
     int32_t want_type_maps;                /* 1: keep the six per-type maps (mapxytoti)          */
     double fov_rad;                        /* fovradiants                                        */
     double ld[SLICER_MAX_PLANES];          /* Lens.ld[isnap]                                     */

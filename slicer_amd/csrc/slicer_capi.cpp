@@ -87,6 +87,20 @@ struct slicer_handle_s {
     unsigned *d_sweep = nullptr;
     DevBuf w_tcounts, w_tbase, w_urand;  // shot-noise thinning (snopt > 0)
     std::vector<float> h_urand;
+    // snopt > 0 with several planes in one pass: the reference draws its deviates plane by plane (outer loop of
+    // createDensityMaps' caller), so the chunks are kept on the device and deposited plane-major when the pass ends
+    struct ThinChunk {
+        int file, type;
+        DevBuf pos, mass;
+        uint64_t n;
+    };
+    struct ThinFile {
+        slicer_file_desc file;
+        int mode[6];
+        float mconst[6];
+    };
+    std::vector<ThinChunk> thin_chunks;
+    std::vector<ThinFile> thin_files;
     uint64_t pend_particles = 0;  // particles behind the pending chunks (bounds their record count)
     DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
     // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
@@ -664,6 +678,124 @@ int flush_pending(slicer_handle h, bool at_file_end = false)
     return SLICER_OK;
 }
 
+// Shot-noise thinning of one chunk into plane slot 0 of (P, T).
+int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg &cfg, const float *d_pos,
+               const float *d_mass, uint64_t n)
+{
+    // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device,
+    // draw on the host from the process-global stream (exactly what the reference consumes), deposit.
+    P.series_max = kSeriesMax15;  // no pre-test on this path either
+    const uint64_t nchunks = (n + 63) / 64;
+    int rc;
+    if ((rc = ensure(h, h->w_tcounts, nchunks * 4)) || (rc = ensure(h, h->w_tbase, (nchunks + 1) * 8)))
+        return rc;
+    {
+        ProfScope ps(h, KN_DIRECT);
+        HIPCHK(h, launch_thin_count(d_pos, n, P, (unsigned *)h->w_tcounts.p, (unsigned long long *)h->w_tbase.p,
+                                    h->d_neg, h->stream));
+    }
+    unsigned long long nsel = 0;
+    HIPCHK(h, hipMemcpyAsync(&nsel, (unsigned long long *)h->w_tbase.p + nchunks, sizeof nsel,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->h_urand.resize(nsel);
+    for (unsigned long long k = 0; k < nsel; k++)
+        h->h_urand[k] = rand() / float(RAND_MAX);
+    if ((rc = ensure(h, h->w_urand, std::max<size_t>(nsel, 1) * 4)))
+        return rc;
+    if (nsel)
+        HIPCHK(h, hipMemcpyAsync(h->w_urand.p, h->h_urand.data(), nsel * 4, hipMemcpyHostToDevice, h->stream));
+    const double pw = std::pow(2, h->desc.snopt);
+    {
+        ProfScope ps(h, KN_DIRECT);
+        HIPCHK(h, launch_thin_deposit(cfg, d_pos, d_mass, n, P, T, (const unsigned long long *)h->w_tbase.p,
+                                      (const float *)h->w_urand.p, 1. / pw, pw, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // h_urand is reused by the next chunk
+    h->algo_mask |= 1 << 3;
+    return SLICER_OK;
+}
+
+bool thin_deferred(slicer_handle h) { return h->desc.snopt > 0 && h->desc.n_planes > 1; }
+
+void thin_drop(slicer_handle h)
+{
+    for (auto &c : h->thin_chunks) {
+        release(c.pos);
+        release(c.mass);
+    }
+    h->thin_chunks.clear();
+    h->thin_files.clear();
+}
+
+// NGP: fold this file's per-type count / mass maps of plane p into its float maps (densitymaps.cpp:405-412 adds each
+// file's mapxyi into the running maps)
+int fold_file_plane(slicer_handle h, int p)
+{
+    bool any = false;
+    for (int t = 0; t < 6; t++)
+        any |= h->file_mode[t] != 0;
+    if (!any)
+        return SLICER_OK;
+    FoldArgs A;
+    memset(&A, 0, sizeof A);
+    for (int t = 0; t < 6; t++) {
+        A.mode[t] = h->file_mode[t];
+        A.mconst[t] = h->file_mconst[t];
+        A.scratch[t] = h->file_mode[t] ? h->planes[p].acc[t].p : nullptr;
+        A.toti[t] = (h->file_mode[t] && h->desc.want_type_maps) ? (float *)h->planes[p].toti[t].p : nullptr;
+    }
+    A.tot = (float *)h->planes[p].tot.p;
+    A.npix2 = h->npix2;
+    ProfScope ps(h, KN_FOLD);
+    HIPCHK(h, launch_fold_ngp(A, h->stream));
+    return SLICER_OK;
+}
+
+// snopt > 0 with several planes: deposit the retained chunks plane-major, files and species in their original order
+// inside each plane -- the order in which the reference (one createDensityMaps call per plane) consumes rand().
+int thin_replay(slicer_handle h)
+{
+    if (!thin_deferred(h) || (h->thin_chunks.empty() && h->thin_files.empty()))
+        return SLICER_OK;
+    const slicer_plane_desc &d = h->desc;
+    const slicer_file_desc file_saved = h->file;
+    int rc = SLICER_OK;
+    for (int p = 0; p < d.n_planes && !rc; p++) {
+        size_t ci = 0;
+        for (size_t f = 0; f < h->thin_files.size() && !rc; f++) {
+            const auto &F = h->thin_files[f];
+            h->file = F.file;
+            for (int t = 0; t < 6; t++) {
+                h->file_mode[t] = F.mode[t];
+                h->file_mconst[t] = F.mconst[t];
+            }
+            for (; ci < h->thin_chunks.size() && h->thin_chunks[ci].file == (int)f && !rc; ci++) {
+                const auto &c = h->thin_chunks[ci];
+                const bool has_mass = c.mass.p != nullptr;
+                PassParams P;
+                make_params(h, c.type, has_mass, P);
+                Targets T;
+                fill_targets(h, c.type, has_mass, T);
+                P.zlo[0] = P.zlo[p];
+                P.zhi[0] = P.zhi[p];
+                P.nrep[0] = P.nrep[p];
+                T.acc[0] = T.acc[p];
+                T.nsel[0] = T.nsel[p];
+                LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
+                rc = thin_chunk(h, P, T, cfg, (const float *)c.pos.p, (const float *)c.mass.p, c.n);
+            }
+            if (!rc && d.mas == SLICER_MAS_NGP)
+                rc = fold_file_plane(h, p);
+        }
+    }
+    h->file = file_saved;
+    for (int t = 0; t < 6; t++)
+        h->file_mode[t] = 0;
+    thin_drop(h);
+    return rc;
+}
+
 int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n)
 {
     const slicer_plane_desc &d = h->desc;
@@ -674,37 +806,25 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     fill_targets(h, type, has_mass, T);
     LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
     if (d.snopt > 0) {
-        // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device,
-        // draw on the host from the process-global stream (exactly what the reference consumes), deposit.
-        P.series_max = kSeriesMax15;  // no pre-test on this path either
-        const uint64_t nchunks = (n + 63) / 64;
-        int rc;
-        if ((rc = ensure(h, h->w_tcounts, nchunks * 4)) || (rc = ensure(h, h->w_tbase, (nchunks + 1) * 8)))
+        if (d.n_planes == 1)
+            return thin_chunk(h, P, T, cfg, d_pos, d_mass, n);
+        // several planes: keep the chunk, thin_replay deposits it once per plane in the reference's order
+        slicer_handle_s::ThinChunk c{};
+        c.file = (int)h->thin_files.size();
+        c.type = type;
+        c.n = n;
+        int rc = ensure(h, c.pos, n * 12);
+        if (!rc && has_mass)
+            rc = ensure(h, c.mass, n * 4);
+        if (rc) {
+            release(c.pos);
+            release(c.mass);
             return rc;
-        {
-            ProfScope ps(h, KN_DIRECT);
-            HIPCHK(h, launch_thin_count(d_pos, n, P, (unsigned *)h->w_tcounts.p, (unsigned long long *)h->w_tbase.p,
-                                        h->d_neg, h->stream));
         }
-        unsigned long long nsel = 0;
-        HIPCHK(h, hipMemcpyAsync(&nsel, (unsigned long long *)h->w_tbase.p + nchunks, sizeof nsel,
-                                 hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->h_urand.resize(nsel);
-        for (unsigned long long k = 0; k < nsel; k++)
-            h->h_urand[k] = rand() / float(RAND_MAX);
-        if ((rc = ensure(h, h->w_urand, std::max<size_t>(nsel, 1) * 4)))
-            return rc;
-        if (nsel)
-            HIPCHK(h, hipMemcpyAsync(h->w_urand.p, h->h_urand.data(), nsel * 4, hipMemcpyHostToDevice, h->stream));
-        const double pw = std::pow(2, d.snopt);
-        {
-            ProfScope ps(h, KN_DIRECT);
-            HIPCHK(h, launch_thin_deposit(cfg, d_pos, d_mass, n, P, T, (const unsigned long long *)h->w_tbase.p,
-                                          (const float *)h->w_urand.p, 1. / pw, pw, h->stream));
-        }
-        HIPCHK(h, hipStreamSynchronize(h->stream));  // h_urand is reused by the next chunk
-        h->algo_mask |= 1 << 3;
+        HIPCHK(h, hipMemcpyAsync(c.pos.p, d_pos, n * 12, hipMemcpyDeviceToDevice, h->stream));
+        if (has_mass)
+            HIPCHK(h, hipMemcpyAsync(c.mass.p, d_mass, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        h->thin_chunks.push_back(c);
         return SLICER_OK;
     }
     BinGeom G;
@@ -899,6 +1019,7 @@ int slicer_destroy(slicer_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
+    thin_drop(h);
     for (auto e : h->ev_pool)
         (void)hipEventDestroy(e);
     for (auto &pl : h->planes) {
@@ -957,11 +1078,6 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
         return fail(h, SLICER_ERR_ARG, "unknown accumulator %d", desc->accum);
     if (desc->snopt < 0 || desc->snopt > 30)
         return fail(h, SLICER_ERR_ARG, "snopt = %d out of range 0..30", desc->snopt);
-    if (desc->snopt > 0 && desc->n_planes != 1)
-        return fail(h, SLICER_ERR_UNSUPPORTED,
-                    "snopt = %d with %d planes in one pass: shot-noise thinning consumes the process-global libc rand() "
-                    "stream in selection order, plane by plane (densitymaps.cpp:387-397); use one plane per pass",
-                    desc->snopt, desc->n_planes);
     if (!(desc->fov_rad > 0))
         return fail(h, SLICER_ERR_ARG, "fov_rad must be > 0");
     for (int p = 0; p < desc->n_planes; p++)
@@ -976,6 +1092,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     h->shared_seen = false;
     h->fixed_shared_set = false;
     h->algo_mask = 0;
+    thin_drop(h);
     h->neg_remote = false;
     h->pend.n = 0;
     h->pend_key = -1;
@@ -1112,29 +1229,25 @@ int slicer_file_end(slicer_handle h)
     if (!h->in_file)
         return fail(h, SLICER_ERR_STATE, "slicer_file_end without slicer_file_begin");
     h->in_file = false;
+    if (thin_deferred(h)) {  // deposited (and folded) plane by plane in thin_replay
+        slicer_handle_s::ThinFile f;
+        f.file = h->file;
+        for (int t = 0; t < 6; t++) {
+            f.mode[t] = h->file_mode[t];
+            f.mconst[t] = h->file_mconst[t];
+        }
+        h->thin_files.push_back(f);
+        return SLICER_OK;
+    }
     if (h->desc.mas == SLICER_MAS_NGP) {
         // the per-file fold needs this file's complete counts
         int rcf = flush_pending(h, true);
         if (rcf)
             return rcf;
-        bool any = false;
-        for (int t = 0; t < 6; t++)
-            any |= h->file_mode[t] != 0;
-        if (any) {
-            for (int p = 0; p < h->desc.n_planes; p++) {
-                FoldArgs A;
-                memset(&A, 0, sizeof A);
-                for (int t = 0; t < 6; t++) {
-                    A.mode[t] = h->file_mode[t];
-                    A.mconst[t] = h->file_mconst[t];
-                    A.scratch[t] = h->file_mode[t] ? h->planes[p].acc[t].p : nullptr;
-                    A.toti[t] = (h->file_mode[t] && h->desc.want_type_maps) ? (float *)h->planes[p].toti[t].p : nullptr;
-                }
-                A.tot = (float *)h->planes[p].tot.p;
-                A.npix2 = h->npix2;
-                ProfScope ps(h, KN_FOLD);
-                HIPCHK(h, launch_fold_ngp(A, h->stream));
-            }
+        for (int p = 0; p < h->desc.n_planes; p++) {
+            int rc = fold_file_plane(h, p);
+            if (rc)
+                return rc;
         }
     }
     return SLICER_OK;
@@ -1152,7 +1265,9 @@ int slicer_plane_finalize(slicer_handle h)
         return SLICER_OK;
     const slicer_plane_desc &d = h->desc;
     {
-        int rcf = flush_pending(h);
+        int rcf = thin_replay(h);
+        if (!rcf)
+            rcf = flush_pending(h);
         if (rcf)
             return rcf;
     }
@@ -1278,7 +1393,8 @@ int slicer_plane_flush(slicer_handle h)
     if (h->finalized)
         return fail(h, SLICER_ERR_STATE, "slicer_plane_flush after slicer_plane_finalize");
     HIPCHK(h, hipSetDevice(h->device));
-    return flush_pending(h);
+    int rc = thin_replay(h);
+    return rc ? rc : flush_pending(h);
 }
 
 namespace {
@@ -1314,7 +1430,9 @@ int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m)
     if (!h->in_plane || h->in_file || h->finalized)
         return fail(h, SLICER_ERR_STATE, "slicer_reduce_meta_get: after the last slicer_file_end, before finalize");
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = flush_pending(h);
+    int rc = thin_replay(h);
+    if (!rc)
+        rc = flush_pending(h);
     if (rc)
         return rc;
     bool live[7];

@@ -507,8 +507,6 @@ def test_empty_inputs_and_state_errors(S):
     assert tot.sum() == 0 and toti.sum() == 0 and cnt.sum() == 0
     with pytest.raises(slicer_amd.SlicerError):
         S.file_end()
-    with pytest.raises(slicer_amd.SlicerError):   # thinning consumes libc rand() plane by plane: one plane per pass
-        S.plane_begin(16, 0.25, [3.0, 3.5], [3.5, 4.0], snopt=1)
     with pytest.raises(slicer_amd.SlicerError):
         S.plane_begin(0, 0.25, [3.0], [4.0])
 
@@ -716,6 +714,60 @@ def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
         kept = ref_toti[1].sum(dtype=np.float64) / (0.0123 * 2 ** snopt) / nsel[1]
         # about one entry in 2^snopt survives (the map misses the few per cent of entries in the border ring)
         assert 0.8 * 2.0 ** -snopt < kept < 1.05 * 2.0 ** -snopt
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+            assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
+        else:
+            assert np.array_equal(tot == 0, ref_tot == 0)
+            d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+            assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
+
+
+@pytest.mark.parametrize("ngp", [True, False])
+def test_shot_noise_thinning_with_several_planes_in_one_pass(S, ngp):
+    """The reference handles one plane per createDensityMaps call, so its rand() stream runs plane-major: all files of
+    plane 0, then all files of plane 1, ...  A pass over three planes must consume the same deviates in the same order
+    (the chunks are kept on the device and deposited plane by plane when the pass ends)."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    snopt, npix, fov = 2, 64, 0.25
+    lds = [3.0, 3.3, 3.6, 4.0]
+    files, first = [], 0
+    for ff in range(3):
+        npart = [1501 if ff != 1 else 0, 30001 + ff, 0, 0, 2001, 0]
+        n = sum(npart)
+        f = dict(npart=npart, massarr=[0.0, 0.0123, 0, 0, 0.3, 0], boxsize=BOX, pos=synth.positions(first, n, BOX))
+        if npart[0]:
+            f["mass"] = {0: np.random.default_rng(ff).uniform(0.001, 0.05, npart[0]).astype(np.float32)}
+        files.append(f)
+        first += n
+    libc.srand(777)
+    ref = []
+    for p in range(3):
+        rc, t, ti, nsel = oracle.create_density_maps(files, 0, 3, npix, True, ngp, lds[p], lds[p + 1], 0, fov,
+                                                     RND["sgn"], RND["face"], RND["center"], RND["rcase"], snopt=snopt)
+        assert rc == 0
+        ref.append((t, ti, nsel))
+    after_ref = libc.rand()
+    libc.srand(777)
+    S.plane_begin(npix, fov, lds[:3], lds[1:], mas=slicer_amd.MAS_NGP if ngp else slicer_amd.MAS_TSC, snopt=snopt,
+                  hydro=True)
+    for f in files:
+        S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        off = 0
+        for t in range(6):
+            if f["npart"][t]:
+                S.deposit_host(t, f["pos"][off:off + f["npart"][t]], f.get("mass", {}).get(t))
+            off += f["npart"][t]
+        S.file_end()
+    assert S.algo_mask() == 0          # nothing has been deposited yet
+    out = [S.plane_read(p) for p in range(3)]
+    assert S.algo_mask() & 8
+    assert libc.rand() == after_ref
+    for p in range(3):
+        tot, toti, cnt = out[p]
+        ref_tot, ref_toti, nsel = ref[p]
+        assert np.array_equal(cnt, nsel) and nsel.sum() > 0
         if ngp:
             assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
             assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
