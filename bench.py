@@ -64,6 +64,9 @@ def parse():
                     help="per-particle masses (type 0, massarr = 0: densitymaps.cpp:358-372) instead of one mass per type")
     ap.add_argument("--shard", default="auto", choices=["auto", "snapshots", "files", "steps"],
                     help="auto: steps (strong scaling, whole steps per rank, finished maps sent to rank 0) when N > 1")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="snapshots in flight per GPU: consecutive steps alternate between this many handles, each on "
+                         "its own HIP stream (kernels of different steps may then run concurrently)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
@@ -264,8 +267,12 @@ def main():
     # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and workspace
     # and works on its own stream; RCCL runs on torch.distributed's communication stream.
     n_handles = 2 if overlap else 1
-    handles = [slicer_amd.Slicer(local_rank, max_chunk=per_file) for _ in range(n_handles)]
-    streams = [torch.cuda.Stream() for _ in range(n_handles)] if overlap else [torch.cuda.current_stream()]
+    n_handles = max(n_handles, a.streams)
+    chunk = per_file
+    if os.environ.get("SLICER_BENCH_CHUNK_LOG2"):  # experiment: several kernel passes per sub-file
+        chunk = min(per_file, 1 << int(os.environ["SLICER_BENCH_CHUNK_LOG2"]))
+    handles = [slicer_amd.Slicer(local_rank, max_chunk=chunk) for _ in range(n_handles)]
+    streams = ([torch.cuda.Stream() for _ in range(n_handles)] if n_handles > 1 else [torch.cuda.current_stream()])
     for S, st in zip(handles, streams):
         S.set_stream(st.cuda_stream)
     S0 = handles[0]

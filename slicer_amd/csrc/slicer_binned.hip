@@ -376,7 +376,21 @@ __device__ __forceinline__ void slow_record(float xs, float ys, float sq, const 
 // particles into one tile) is split into parts of <= kItemRecs records, each deposited by its own workgroup
 // into its own LDS tile and flushed atomically, so that one heavy tile neither serialises on one CU nor
 // stretches the kernel's tail.  Empty bins get no item.
-constexpr unsigned kItemRecs = 16384;
+#ifndef SLICER_ITEM_RECS
+#define SLICER_ITEM_RECS 16384
+#endif
+constexpr unsigned kItemRecs = SLICER_ITEM_RECS;
+#ifndef SLICER_WHOLE_RECS
+#define SLICER_WHOLE_RECS 65536
+#endif
+// ... but a bin of up to kWholeRecs records stays whole: every part pays for zeroing and flushing a tile of its own
+// (536 us against 554 us for the uniform headline case), while only a bin far beyond the usual load needs many hands
+constexpr unsigned kWholeRecs = SLICER_WHOLE_RECS;
+#ifndef SLICER_MERGE_RECS
+#define SLICER_MERGE_RECS 131072
+#endif
+// bins beyond about SLICER_MERGE_RECS records (a halo core) go through the wave-level pre-reduction
+constexpr unsigned kMergeParts = SLICER_MERGE_RECS / kItemRecs > 2 ? SLICER_MERGE_RECS / kItemRecs : 2;
 
 struct TileItems {
     unsigned *nparts;   // [nbins] parts of every bin (0 = empty: no work item)
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, T
     unsigned tot = 0;
     for (int c = 0; c < L.n; c++)
         tot += L.base[c][b + 1] - L.base[c][b];
-    const unsigned np = (tot + kItemRecs - 1) / kItemRecs;
+    const unsigned np = tot <= kWholeRecs ? (tot != 0) : (tot + kItemRecs - 1) / kItemRecs;
     I.nparts[b] = np;
     if (np > 1) {
         const unsigned at = atomicAdd(I.n_extra, np - 1);
@@ -436,12 +450,13 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
             float mr[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                // clamped, unconditional loads: a load under a branch makes the compiler drain the memory queue
+                // before each one (s_waitcnt vmcnt(0)), which serialises the U loads
                 const unsigned i = i0 + u * kTileBlock + tid;
-                if (i < end) {
-                    r[u] = sxy[i];
-                    if (HAS_MASS)
-                        mr[u] = sm[i];
-                }
+                const unsigned ic = i < end ? i : end - 1;
+                r[u] = sxy[ic];
+                if (HAS_MASS)
+                    mr[u] = sm[ic];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -633,6 +648,20 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
     }
 }
 
+// Visit every cell of a W x H LDS tile (W = 64 k + 2): a wave per row with its lanes along the row for the first W - 2
+// columns, then the two halo columns on the right as one dense range -- no division by the run-time row length and no
+// nearly empty trip for the two cells beyond a multiple of 64.
+template <typename Fn>
+__device__ __forceinline__ void for_each_tile_cell(int W, int H, Fn &&fn)
+{
+    const int tid = threadIdx.x;
+    for (int row = tid >> 6; row < H; row += kTileBlock / 64)
+        for (int col = tid & 63; col < W - 2; col += 64)
+            fn(row, col);
+    for (int i = tid; i < 2 * H; i += kTileBlock)
+        fn(i >> 1, W - 2 + (i & 1));
+}
+
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
                                                              TileItems I, NgpFold F)
@@ -679,7 +708,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
     // pre-reduction only for bins far beyond a tile's usual load (>= 8 parts = 131072 records: a halo core); a bin that
     // is merely split in two or three is faster through the plain loop (--clustered: 810 us with, 700 us without)
-    if (nparts >= 8)
+    if (nparts >= kMergeParts)
         tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap);
     else if (MAS == kNGP || interior)
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap);
@@ -702,32 +731,32 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         // NGP fold in place: this workgroup is the only one that touches these pixels in this launch (NGP records hit
         // cells of their own tile only, and the tile is not split), so plain read-modify-writes in file order are exact
         float *tot = F.tot[plane], *toti = F.toti[plane];
-        for (int i = tid; i < cells; i += kTileBlock) {
-            const unsigned k = (unsigned)tile[i];
+        auto fold = [&](int row, int col) {
+            const unsigned k = (unsigned)tile[row * W + col];
             if (k == 0)
-                continue;
-            const size_t idx = (size_t)(x0 - 1 + i % W) + (size_t)nn * (size_t)(y0 - 1 + i / W);
+                return;
+            const size_t idx = (size_t)(x0 - 1 + col) + (size_t)nn * (size_t)(y0 - 1 + row);
             const float v = ngp_seq_sum(k, F.m);
             tot[idx] = tot[idx] + v;
             if (toti)
                 toti[idx] = toti[idx] + v;
-        }
+        };
+        for_each_tile_cell(W, H, fold);
         return;
     }
     // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
-    for (int i = tid; i < cells; i += kTileBlock) {
-        const lds_t v = tile[i];
-        if (v == (lds_t)0)
-            continue;
-        const int py = y0 - 1 + i / W;
-        const int px = x0 - 1 + i % W;
-        if (px < 0 || px >= nn || py < 0 || py >= nn)
-            continue;
+    auto flush = [&](int row, int col) {
+        const lds_t v = tile[row * W + col];
+        const int px = x0 - 1 + col, py = y0 - 1 + row;
+        if (v == (lds_t)0 || px < 0 || px >= nn || py < 0 || py >= nn)
+            return;
+        acc_t *cell = gmap + (size_t)px + (size_t)nn * (size_t)py;
         if (kIntCells<ACC>)  // exact tile sum -> one rounding to the accumulator type
-            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)((double)v * P.tile_inv_scale));
+            atomicAdd(cell, (acc_t)((double)v * P.tile_inv_scale));
         else
-            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (acc_t)v);
-    }
+            atomicAdd(cell, (acc_t)v);
+    };
+    for_each_tile_cell(W, H, flush);
 }
 
 // NGP fold of the tiles that were split over several workgroups (their parts added counts to the global count map):

@@ -149,7 +149,10 @@ hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, i
                               const BinWorkspace &W, const Targets &T, hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
-constexpr int kMaxPending = 8;
+#ifndef SLICER_MAX_PENDING
+#define SLICER_MAX_PENDING 8
+#endif
+constexpr int kMaxPending = SLICER_MAX_PENDING;
 struct PendingList {
     int n;
     const float2 *sxy[kMaxPending];
