@@ -164,7 +164,9 @@ int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
 
 /* Which deposit algorithms ran since slicer_plane_begin: bit SLICER_ALGO_DIRECT, bit SLICER_ALGO_BINNED
  * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0); bits 4 / 5 tell which project+bin kernel the
- * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip). */
+ * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip); bit 6: a tile
+ * kernel launch kept its tiles as integer (u64) cells (constant-mass TSC, F32 / F64 accumulators, enough records per
+ * tile; SLICER_K4_INT=0 / 2 in the environment forbids / forces them -- a tuning and test knob). */
 int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
 /* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
  * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */

@@ -879,8 +879,9 @@ size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles)
 
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
                                const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,
-                               uint64_t total_particles, hipStream_t s)
+                               uint64_t total_particles, bool *int_cells_used, hipStream_t s)
 {
+    *int_cells_used = false;
     // total_particles bounds the number of records (each particle emits at most one on this path).  Workspace:
     // two counters (used alternately: launch `epoch` reads [epoch & 1] and zeroes the other one) | nparts | extra
     const unsigned max_items = (unsigned)((uint64_t)G.nbins + total_particles / kItemRecs + 1);
@@ -903,13 +904,19 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
         }
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }
-    // constant-mass TSC in the F32 / F64 modes: integer tile cells (SLICER_K4_INT=0 keeps the f64 cells)
-    static const bool int_cells = !(getenv("SLICER_K4_INT") && atoi(getenv("SLICER_K4_INT")) == 0);
+    // constant-mass TSC in the F32 / F64 modes: integer tile cells (SLICER_K4_INT=0 keeps the f64 cells, =2 forces the
+    // integer ones).  They pay where the records dominate; a launch with few records per tile (large maps: 8192^2 x 4
+    // planes has ~3000) is mostly tile zeroing and flushing, where the u64 -> float conversion of every cell costs
+    // more than the cheaper LDS atomic saves (1429 against 1221 us there).
+    const char *env_int = getenv("SLICER_K4_INT");
+    const int int_mode = env_int ? atoi(env_int) : 1;
+    const bool int_cells = int_mode == 2 || (int_mode == 1 && total_particles / (uint64_t)G.nbins >= 8192);
     if (int_cells && !cfg.has_mass && (cfg.acc == kF32 || cfg.acc == kF64)) {
         bool same_mass = true;  // one quantum per launch: all pending chunks carry the same constant mass
         for (int c = 1; c < L.n; c++)
             same_mass = same_mass && L.mconst[c] == L.mconst[0];
         if (same_mass && L.mconst[0] == P.mconst) {
+            *int_cells_used = true;
             if (cfg.acc == kF32)
                 return launch_k4<kTSC, kF32I>(pow2, false, P, G, L, T, I, F, max_items, s);
             return launch_k4<kTSC, kF64I>(pow2, false, P, G, L, T, I, F, max_items, s);

@@ -677,8 +677,11 @@ int flush_group(slicer_handle h, int group, bool at_file_end)
     }
     {
         ProfScope ps(h, KN_TILE);
-        HIPCHK(h, launch_tile_deposit(Q.cfg, Q.P, Q.G, Q.L, Q.T, F, h->w_items.p,
-                                      h->items_epoch++, Q.particles, h->stream));
+        bool int_cells = false;
+        HIPCHK(h, launch_tile_deposit(Q.cfg, Q.P, Q.G, Q.L, Q.T, F, h->w_items.p, h->items_epoch++, Q.particles,
+                                      &int_cells, h->stream));
+        if (int_cells)
+            h->algo_mask |= 1 << 6;
     }
     Q.L.n = 0;
     Q.key = -1;

@@ -26,7 +26,9 @@ from slicer_amd import synth
 pytestmark = pytest.mark.gpu
 
 BOX = 1000.0
-RND = dict(sgn=(-1, 1, -1), face=3, center=(0.3, 0.6, 0.1), rcase=3.0)
+# centres as the reference draws them: f32 values (rand() / float(RAND_MAX), densitymaps.cpp:188-190) -- the case the fast
+# project+bin kernel serves, and what bench.py uses
+RND = dict(sgn=(-1, 1, -1), face=3, center=tuple(float(np.float32(c)) for c in (0.3, 0.6, 0.1)), rcase=3.0)
 LDS, LD2S = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
 FOV, MASS, SEED = 0.25, 0.0123, 0x51CE2
 U24 = 2.0 ** -24
@@ -64,7 +66,10 @@ def headline_ref():
 
 
 @pytest.mark.parametrize("accum", ["f32", "f64", "fixed64"])
-def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum):
+def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum, monkeypatch):
+    # one sub-file alone has 2048 particles per (plane, tile) bin; the benchmark flushes eight at once (16384 per bin) and
+    # therefore keeps integer tile cells in the F32 / F64 modes: force that kernel here
+    monkeypatch.setenv("SLICER_K4_INT", "2")
     pos, ref = headline_ref
     n = len(pos)
     d = S.to_device(pos)
@@ -91,6 +96,8 @@ def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref,
         worst = max(worst, float((dd[nz] / tot[nz]).max()))
         kmax = max(kmax, int(k.max()))
     S.free(d)
+    # the benchmark's tile kernel: integer LDS cells in the F32 / F64 modes (bit 6), the fast project+bin kernel (bit 4)
+    assert bool(S.algo_mask() & 64) == (accum != "fixed64") and S.algo_mask() & 16
     gate = max(1e-6, 2.0 * U24 * np.sqrt(kmax))
     print(f"headline 4096^2 TSC 4 planes BINNED accum={accum}: max_rel_dpixel {worst:.3e} (k_max {kmax}, gate {gate:.2e})")
     assert worst <= gate

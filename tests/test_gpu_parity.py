@@ -36,6 +36,14 @@ def S():
     s.close()
 
 
+@pytest.fixture(autouse=True)
+def integer_tile_cells(monkeypatch):
+    """The tile kernel keeps integer (u64) LDS cells only when a launch has enough records per tile (the benchmark
+    sizes); the parity cases here are small, so force them (SLICER_K4_INT is read on every launch) -- this is the
+    path the headline configuration runs.  test_tile_cell_kind_follows_the_load checks the automatic choice."""
+    monkeypatch.setenv("SLICER_K4_INT", "2")
+
+
 def run_gpu(S, files, npix, fov, ld, ld2, ngp=False, accum=slicer_amd.ACC_F32, algo=slicer_amd.ALGO_AUTO,
             nrep=0, hydro=False, rnd=RND, want_type_maps=True, device_resident=False):
     ld = list(np.atleast_1d(ld))
@@ -986,3 +994,24 @@ def test_fast_and_general_project_bin_kernels_agree(S, general, monkeypatch):
             ref_tot, _, nsel = run_oracle([f], 512, 0.25, lds[p], ld2s[p], ngp=True, rnd=rnd)
             assert np.array_equal(out[p][2], nsel)
             assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), (rnd, p)
+
+
+def test_tile_cell_kind_follows_the_load(S, monkeypatch):
+    """Integer tile cells need >= 8192 particles per (plane, tile) bin in a launch (slicer_plane_algo_mask bit 6);
+    both kinds of cells give maps inside the TSC bar and bit-identical fixed-point sums of their own kind."""
+    f = one_type_file(1 << 20)
+    ref_tot, _, nsel = run_oracle([f], 256, 0.25, 3.0, 4.0)
+    masks, maps = {}, {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("SLICER_K4_INT", mode)
+        (tot, _, cnt), = run_gpu(S, [f], 256, 0.25, [3.0], [4.0], algo=slicer_amd.ALGO_BINNED)
+        masks[mode], maps[mode] = S.algo_mask(), tot
+        assert np.array_equal(cnt, nsel)
+        d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+        assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / 256 ** 2) * ref_tot)
+    # automatic choice: 2^20 particles over the 512 bins of a 256^2 map stay below 8192 per bin, over the 32 bins of a
+    # 64^2 map they do not
+    assert not masks["0"] & 64 and masks["2"] & 64 and not masks["1"] & 64
+    monkeypatch.setenv("SLICER_K4_INT", "1")
+    run_gpu(S, [f], 64, 0.25, [3.0], [4.0], algo=slicer_amd.ALGO_BINNED)
+    assert S.algo_mask() & 64
