@@ -402,7 +402,7 @@ struct TileItems {
 // Work items of the tile kernel: part 0 of bin b is workgroup b; the further parts of heavy bins are appended to a
 // list with one atomic add per heavy bin (their order does not matter), so that the builder is a plain parallel
 // kernel instead of a single-workgroup scan.
-__global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, TileItems I)
+__global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, TileItems I, int whole)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b == 0)
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, T
     unsigned tot = 0;
     for (int c = 0; c < L.n; c++)
         tot += L.base[c][b + 1] - L.base[c][b];
-    const unsigned np = tot <= kWholeRecs ? (tot != 0) : (tot + kItemRecs - 1) / kItemRecs;
+    // (whole: the launch folds NGP counts file by file inside the tile kernel, which needs every tile in one workgroup)
+    const unsigned np = (whole || tot <= kWholeRecs) ? (tot != 0) : (tot + kItemRecs - 1) / kItemRecs;
     I.nparts[b] = np;
     if (np > 1) {
         const unsigned at = atomicAdd(I.n_extra, np - 1);
@@ -429,7 +430,7 @@ template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK>
 __device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
                                                 typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                 unsigned nparts, int x0, int y0, int W, unsigned *s_nslow,
-                                                uint2 *s_slow, typename AccT<ACC>::type *gmap)
+                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, int c_begin, int c_end)
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
@@ -437,7 +438,7 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     constexpr int U = 4;  // records in flight per lane
     // (dealing the waves to the pending chunks, so that all runs stream in at once, measured 699 us against 665 us for
     // this chunk-by-chunk walk: the kernel is bound by the LDS atomic pipe, not by the loads)
-    for (int c = 0; c < L.n; c++) {
+    for (int c = c_begin; c < c_end; c++) {
         // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts)
         const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
         const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
@@ -706,14 +707,93 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 
     // the halo [x0 - 1, x0 + W - 2] x [y0 - 1, y0 + H - 2] inside the map: no cell of this tile needs the edge test
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
+    if (MAS == kNGP && ACC == kCountU32) {
+        // NGP counts: one sub-file after the other (chunks of a file are neighbours in the list).  A file marked `fold`
+        // is folded into the f32 maps right here -- this workgroup is the only one that touches these pixels in this
+        // launch (NGP records hit cells of their own tile only, and no tile is split when F.on), so the pixel values
+        // travel in registers from the first file to the last: lane `tid` owns the tile's cells tid, tid + 1024, ...
+        // Any other file's counts go to the global count map.
+        constexpr int CPT = 16;  // 128 x 128 cells / 1024 lanes
+        float rt[CPT], ri[CPT];
+        float *tot = F.tot[plane], *toti = F.toti[plane];
+        const int tw = 1 << G.tw_log2, ncell = tw << G.th_log2;
+        auto owned = [&](int j, int &cell, size_t &idx) {  // -> lane's j-th cell lies inside the map
+            const int i = j * kTileBlock + tid;
+            const int row = i >> G.tw_log2, col = i & (tw - 1);
+            cell = (row + 1) * W + col + 1;
+            idx = (size_t)(x0 + col) + (size_t)nn * (size_t)(y0 + row);
+            return i < ncell && x0 + col < nn && y0 + row < nn;
+        };
+        if (F.on) {
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                int cell;
+                size_t idx;
+                const bool in = owned(j, cell, idx);
+                rt[j] = in ? tot[idx] : 0.0f;
+                ri[j] = (in && toti) ? toti[idx] : 0.0f;
+            }
+        }
+        unsigned touched = 0;
+        for (int c0 = 0; c0 < L.n;) {
+            int c1 = c0 + 1;
+            while (c1 < L.n && L.file_id[c1] == L.file_id[c0])
+                c1++;
+            tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow,
+                                                             gmap, c0, c1);
+            __syncthreads();
+            if (F.on && L.fold[c0]) {
+                const float m = L.mconst[c0];
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    int cell;
+                    size_t idx;
+                    if (!owned(j, cell, idx))
+                        continue;
+                    const unsigned k = (unsigned)tile[cell];
+                    if (k == 0)
+                        continue;
+                    tile[cell] = (lds_t)0;
+                    const float v = ngp_seq_sum(k, m);
+                    rt[j] = rt[j] + v;  // tot += mapxyi, toti += mapxyi   densitymaps.cpp:511-513
+                    ri[j] = ri[j] + v;
+                    touched |= 1u << j;
+                }
+            } else {
+                auto flush = [&](int row, int col) {
+                    const unsigned k = (unsigned)tile[row * W + col];
+                    if (k == 0)
+                        return;
+                    tile[row * W + col] = (lds_t)0;
+                    atomicAdd(gmap + (size_t)(x0 - 1 + col) + (size_t)nn * (size_t)(y0 - 1 + row), (acc_t)k);
+                };
+                for_each_tile_cell(W, H, flush);
+            }
+            __syncthreads();
+            c0 = c1;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; j++)
+            if (touched >> j & 1u) {
+                int cell;
+                size_t idx;
+                (void)owned(j, cell, idx);
+                tot[idx] = rt[j];
+                if (toti)
+                    toti[idx] = ri[j];
+            }
+        return;
+    }
     // pre-reduction only for bins far beyond a tile's usual load (>= 8 parts = 131072 records: a halo core); a bin that
     // is merely split in two or three is faster through the plain loop (--clustered: 810 us with, 700 us without)
     if (nparts >= kMergeParts)
         tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap);
     else if (MAS == kNGP || interior)
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap);
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
+                                                         0, L.n);
     else
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap);
+        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
+                                                        0, L.n);
     __syncthreads();
     if (kIntCells<ACC>) {
         // the records noted in the loop: those of their contributions that are exact multiples of the quantum go into
@@ -727,23 +807,6 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         __syncthreads();
     }
 
-    if (ACC == kCountU32 && F.on && nparts == 1) {
-        // NGP fold in place: this workgroup is the only one that touches these pixels in this launch (NGP records hit
-        // cells of their own tile only, and the tile is not split), so plain read-modify-writes in file order are exact
-        float *tot = F.tot[plane], *toti = F.toti[plane];
-        auto fold = [&](int row, int col) {
-            const unsigned k = (unsigned)tile[row * W + col];
-            if (k == 0)
-                return;
-            const size_t idx = (size_t)(x0 - 1 + col) + (size_t)nn * (size_t)(y0 - 1 + row);
-            const float v = ngp_seq_sum(k, F.m);
-            tot[idx] = tot[idx] + v;
-            if (toti)
-                toti[idx] = toti[idx] + v;
-        };
-        for_each_tile_cell(W, H, fold);
-        return;
-    }
     // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
     auto flush = [&](int row, int col) {
         const lds_t v = tile[row * W + col];
@@ -757,40 +820,6 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
             atomicAdd(cell, (acc_t)v);
     };
     for_each_tile_cell(W, H, flush);
-}
-
-// NGP fold of the tiles that were split over several workgroups (their parts added counts to the global count map):
-// one workgroup per listed tile (the list entries with part == 1 name every split bin exactly once).
-__global__ __launch_bounds__(256) void k_fold_heavy_tiles(PassParams P, BinGeom G, Targets T, TileItems I, NgpFold F)
-{
-    const unsigned n = *I.n_extra;
-    for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
-        const uint2 item = I.extra[j];
-        if (item.y != 1)
-            continue;
-        const int bin = (int)item.x;
-        const int unit = bin / G.tiles_per_unit, t = bin % G.tiles_per_unit;
-        const int plane = unit / G.units_per_plane, band = unit % G.units_per_plane;
-        const int x0 = (t % G.ntx) << G.tw_log2;
-        const int y0 = (band * G.rows_per_unit + t / G.ntx) << G.th_log2;
-        const int tw = 1 << G.tw_log2, th = 1 << G.th_log2;
-        unsigned *cnt = reinterpret_cast<unsigned *>(T.acc[plane]);
-        float *tot = F.tot[plane], *toti = F.toti[plane];
-        for (int i = threadIdx.x; i < tw * th; i += 256) {
-            const int px = x0 + i % tw, py = y0 + i / tw;
-            if (px >= P.nn || py >= P.nn)
-                continue;
-            const size_t idx = (size_t)px + (size_t)P.nn * (size_t)py;
-            const unsigned k = cnt[idx];
-            if (k == 0)
-                continue;
-            cnt[idx] = 0;
-            const float v = ngp_seq_sum(k, F.m);
-            tot[idx] = tot[idx] + v;
-            if (toti)
-                toti[idx] = toti[idx] + v;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -891,16 +920,11 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
     I.next_n_extra = counters + ((epoch + 1u) & 1u);
     I.nparts = counters + 4;
     I.extra = reinterpret_cast<uint2 *>(I.nparts + G.nbins + (G.nbins & 1));
-    k_build_items<<<(G.nbins + 255) / 256, 256, 0, s>>>(L, G.nbins, I);
+    k_build_items<<<(G.nbins + 255) / 256, 256, 0, s>>>(L, G.nbins, I, (cfg.mas == kNGP && cfg.acc == kCountU32 && F.on) ? 1 : 0);
     const bool pow2 = P.pow2 != 0;
     if (cfg.mas == kNGP) {
         if (cfg.acc == kCountU32) {
-            hipError_t e = launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, F, max_items, s);
-            if (e == hipSuccess && F.on) {
-                k_fold_heavy_tiles<<<64, 256, 0, s>>>(P, G, T, I, F);
-                e = hipGetLastError();
-            }
-            return e;
+            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, F, max_items, s);
         }
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }

@@ -64,7 +64,8 @@ struct slicer_handle_s {
     int algo_mask = 0;            // bit (1 << SLICER_ALGO_*) of every algorithm that ran in this pass; bit 3 = thinning
     bool neg_remote = false;      // another rank reported the negativity guard (slicer_reduce_meta_set)
     int file_mode[6] = {};        // NGP fold mode of the current file
-    bool file_partial_flush[6] = {};  // NGP: part of this file's records of the species were flushed before file_end
+    bool file_partial_flush[6] = {};  // NGP: some of this file's records of the species went to the global count map
+    unsigned file_serial = 0;         // counts slicer_file_begin calls (PendingList.file_id)
     float file_mconst[6] = {};
     int fixed_exp[6] = {};
     int fixed_exp_shared = 0;
@@ -639,32 +640,46 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int group, int slot, ui
     return SLICER_OK;
 }
 
+bool ngp_foldable(slicer_handle h, int type)
+{
+    int species = 0;
+    for (int t = 0; t < 6; t++)
+        species += h->file.npart[t] > 0;
+    return species == 1 && h->file.npart[type] > 0 && !h->file_partial_flush[type] && !env_int("SLICER_NGP_GENERAL");
+}
+
+// NGP: some of the open file's records of this species are (about to be) in the global count map, so none of them may
+// be folded inside the tile kernel: the per-file sum needs the file's complete count per pixel (k_fold_ngp does it)
+void ngp_spoil_file(slicer_handle h, int type)
+{
+    h->file_partial_flush[type] = true;
+    for (auto &Q : h->pg)
+        if (Q.L.n && Q.key < 12 && Q.key / 2 == type)
+            for (int c = 0; c < Q.L.n; c++)
+                if (!Q.L.done[c])
+                    Q.L.fold[c] = 0;
+}
+
 // Deposit the pending (binned) chunks of one plane group with one tile-kernel launch.
-int flush_group(slicer_handle h, int group, bool at_file_end)
+int flush_group(slicer_handle h, int group)
 {
     auto &Q = h->pg[group];
     if (Q.L.n == 0)
         return SLICER_OK;
-    // NGP fast path (see NgpFold): constant mass, the sub-file holds this one species only, and this flush carries all
-    // of its records (a flush forced in mid-file does not: its counts are partial)
     NgpFold F;
     memset(&F, 0, sizeof F);
-    const int ptype = Q.key / 2;
     if (Q.cfg.mas == kNGP && Q.cfg.acc == kCountU32 && Q.key < 12) {
-        int species = 0;
-        for (int t = 0; t < 6; t++)
-            species += h->file.npart[t] > 0;
-        if (at_file_end && species == 1 && h->file.npart[ptype] > 0 && !h->file_partial_flush[ptype] &&
-            Q.np == h->desc.n_planes && !env_int("SLICER_NGP_GENERAL")) {
-            F.on = 1;
-            F.m = h->file_mconst[ptype];
-            for (int p = 0; p < Q.np; p++) {
-                F.tot[p] = (float *)h->planes[Q.p0 + p].tot.p;
-                F.toti[p] = h->desc.want_type_maps ? (float *)h->planes[Q.p0 + p].toti[ptype].p : nullptr;
+        const int ptype = Q.key / 2;
+        for (int c = 0; c < Q.L.n; c++)
+            if (!Q.L.done[c]) {  // a flush in mid-file: the open file's counts are partial
+                ngp_spoil_file(h, ptype);
+                break;
             }
-            h->file_mode[ptype] = 0;  // folded here: slicer_file_end has nothing left to do for this species
-        } else {
-            h->file_partial_flush[ptype] = true;
+        for (int c = 0; c < Q.L.n; c++)
+            F.on |= Q.L.fold[c];
+        for (int p = 0; p < Q.np; p++) {
+            F.tot[p] = (float *)h->planes[Q.p0 + p].tot.p;
+            F.toti[p] = h->desc.want_type_maps ? (float *)h->planes[Q.p0 + p].toti[ptype].p : nullptr;
         }
     }
     bool fresh = false;
@@ -689,10 +704,10 @@ int flush_group(slicer_handle h, int group, bool at_file_end)
     return SLICER_OK;
 }
 
-int flush_pending(slicer_handle h, bool at_file_end = false)
+int flush_pending(slicer_handle h)
 {
     for (int g = 0; g < SLICER_MAX_PLANES; g++) {
-        int rc = flush_group(h, g, at_file_end);
+        int rc = flush_group(h, g);
         if (rc)
             return rc;
     }
@@ -838,7 +853,7 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
     const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
     const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
     int rc;
-    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending) && (rc = flush_group(h, group, false)))
+    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending) && (rc = flush_group(h, group)))
         return rc;
     const int slot = Q.L.n;
     BinWorkspace W;
@@ -875,6 +890,13 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
     Q.L.sm[slot] = has_mass ? W.sm : nullptr;
     Q.L.base[slot] = W.base;
     Q.L.mconst[slot] = P.mconst;
+    Q.L.file_id[slot] = (unsigned short)h->file_serial;
+    Q.L.done[slot] = 0;
+    Q.L.fold[slot] = cfg.mas == kNGP && cfg.acc == kCountU32 && ngp_foldable(h, type);
+    if (Q.L.fold[slot] && G.tw_log2 + G.th_log2 > 14) {  // the tile kernel keeps 16 pixels per lane (tile size overrides)
+        ngp_spoil_file(h, type);
+        Q.L.fold[slot] = 0;
+    }
     Q.L.sm_const[slot] = P.sm_const;
     Q.L.n = slot + 1;
     Q.particles += n * (uint64_t)(G.region / G.batch);  // bounds the records behind the pending chunks
@@ -947,6 +969,8 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         binned = false;  // several launches are not worth it for a tiny chunk
     h->algo_mask |= 1 << (binned ? SLICER_ALGO_BINNED : SLICER_ALGO_DIRECT);
     if (!binned) {
+        if (d.mas == SLICER_MAS_NGP)
+            ngp_spoil_file(h, type);  // counts into the global map
         ProfScope ps(h, KN_DIRECT);
         P.series_max = kSeriesMax15;  // no pre-test on this path: entries far outside the field reach project()
         HIPCHK(h, launch_direct(cfg, d_pos, d_mass, n, P, T, h->stream));
@@ -1219,6 +1243,7 @@ int slicer_file_begin(slicer_handle h, const slicer_file_desc *file)
             return fail(h, SLICER_ERR_ARG, "sgn[%d] = %d is not +-1", a, file->sgn[a]);
     h->file = *file;
     h->in_file = true;
+    h->file_serial++;
     for (int t = 0; t < 6; t++) {
         h->file_mode[t] = 0;
         h->file_partial_flush[t] = false;
@@ -1327,14 +1352,30 @@ int slicer_file_end(slicer_handle h)
         return SLICER_OK;
     }
     if (h->desc.mas == SLICER_MAS_NGP) {
-        // the per-file fold needs this file's complete counts
-        int rcf = flush_pending(h, true);
-        if (rcf)
-            return rcf;
-        for (int p = 0; p < h->desc.n_planes; p++) {
-            int rc = fold_file_plane(h, p);
-            if (rc)
-                return rc;
+        for (auto &Q : h->pg)
+            for (int c = 0; c < Q.L.n; c++)
+                Q.L.done[c] = 1;  // every chunk still pending belongs to a closed file now
+        // A species whose counts all wait in the pending lists marked `fold` needs nothing more here: the tile kernel
+        // folds them, file by file, when the lists are flushed (NgpFold).  Anything else has counts in the global count
+        // maps (or is about to: its pending chunks carry fold = 0) and is folded by the map-wide kernel, now.
+        bool need_kernel = false;
+        for (int t = 0; t < 6; t++) {
+            if (!h->file_mode[t])
+                continue;
+            if (h->file_mode[t] == 1 && ngp_foldable(h, t))
+                h->file_mode[t] = 0;
+            else
+                need_kernel = true;
+        }
+        if (need_kernel) {
+            int rcf = flush_pending(h);
+            if (rcf)
+                return rcf;
+            for (int p = 0; p < h->desc.n_planes; p++) {
+                int rc = fold_file_plane(h, p);
+                if (rc)
+                    return rc;
+            }
         }
     }
     return SLICER_OK;

@@ -160,18 +160,25 @@ struct PendingList {
     const unsigned *base[kMaxPending];
     float mconst[kMaxPending];    // (float)massarr[t] of the chunk's file
     float sm_const[kMaxPending];  // sqrtf(mconst)
+    // NGP counts only (see NgpFold): chunks of one sub-file carry the same file_id and sit next to each other; fold = the
+    // file's counts may be folded into the f32 maps while they are in LDS (its records are complete in this list)
+    unsigned short file_id[kMaxPending];
+    unsigned char fold[kMaxPending];
+    unsigned char done[kMaxPending];  // host bookkeeping: slicer_file_end has closed the chunk's file
 };
 size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles);
-// NGP with one constant mass, all records of a (sub-file, species) in one flush, the sub-file holding no other species:
-// the tile kernel folds its counts straight into the f32 maps while the tile is in LDS -- pixel value = the k-fold
-// sequential f32 sum s <- fl(s + m) (utilities.cpp:75), tot += it, toti += it (densitymaps.cpp:511-513 with five zero
-// maps) -- instead of adding them to a global count map that a map-wide pass folds afterwards.  Tiles split over
-// several workgroups (halo cores) still go through the count map; k_fold_heavy_tiles folds just those.
+// NGP counts with one constant mass per species: the reference's pixel value is, file by file, the k-fold sequential
+// f32 sum s <- fl(s + m) of the file's k entries in the pixel (utilities.cpp:75), added to tot and toti
+// (densitymaps.cpp:511-513).  For a sub-file that holds one species only and whose records are complete in the pending
+// list (PendingList.fold), the tile kernel does exactly that while the counts are in LDS -- one file after the other,
+// in order, each tile owned by one workgroup (no split parts in such a launch) -- instead of adding them to a global
+// count map that a map-wide pass folds afterwards; sub-files wait in the pending list, so a snapshot's files share one
+// launch.  Files that do not qualify (several species, a chunk through the fused kernel, a flush in mid-file) go
+// through the count map and k_fold_ngp as before.
 struct NgpFold {
-    int on;
-    float m;
-    float *tot[kMaxPlanes];
-    float *toti[kMaxPlanes];  // or nullptr (per-type maps not kept)
+    int on;                    // some pending chunk has fold set
+    float *tot[kMaxPlanes];    // all-types map of each plane of the group
+    float *toti[kMaxPlanes];   // this species' map, or null
 };
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
                                const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,

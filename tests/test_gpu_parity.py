@@ -1015,3 +1015,25 @@ def test_tile_cell_kind_follows_the_load(S, monkeypatch):
     monkeypatch.setenv("SLICER_K4_INT", "1")
     run_gpu(S, [f], 64, 0.25, [3.0], [4.0], algo=slicer_amd.ALGO_BINNED)
     assert S.algo_mask() & 64
+
+
+def test_ngp_file_with_a_binned_and_a_tiny_chunk():
+    """A sub-file one chunk and a bit long: the big chunk runs the binned kernels, the remainder (< 65536 particles)
+    the fused kernel into the global count map.  The per-file NGP fold (s <- fl(s + m) k times per pixel,
+    utilities.cpp:75) must see the file's complete counts: folding the two parts separately is not the same sum."""
+    S2 = slicer_amd.Slicer(0, max_chunk=100000)
+    try:
+        files = [one_type_file(130000, clustered=True), one_type_file(100000 + 7, first=130000, clustered=True),
+                 one_type_file(90000, first=230007)]
+        npix = 64   # few pixels: many particles per pixel, where the order of the f32 additions shows
+        for types in (True, False):
+            out = run_gpu(S2, files, npix, 0.25, [3.0, 3.5], [3.5, 4.0], ngp=True, want_type_maps=types)
+            assert S2.algo_mask() & 6 == 6      # both the binned and the fused kernel ran
+            for p, (ld, ld2) in enumerate(((3.0, 3.5), (3.5, 4.0))):
+                ref_tot, ref_toti, nsel = run_oracle(files, npix, 0.25, ld, ld2, ngp=True)
+                assert np.array_equal(out[p][2], nsel)
+                assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), (types, p)
+                if types:
+                    assert np.array_equal(out[p][1].view(np.uint32), ref_toti.view(np.uint32))
+    finally:
+        S2.close()
