@@ -56,3 +56,47 @@ for seed in range(300, 380):
             print("FAIL hydro seed", seed, "plane", p, flush=True)
 print("hydro flavour done, failures:", bad)
 S.close()
+
+# third flavour: NGP under SLICER_ALGO_AUTO with sub-files of one or several species, small kernel-pass chunks (files in
+# several chunks, tiny remainders through the fused kernel), with and without per-type maps, sometimes overlapping
+# slabs: every map bit for bit against the oracle (the per-file folds: inside the tile kernel, through the count map,
+# and mixtures of both in one pass)
+bad = 0
+for seed in range(400, 400 + (int(sys.argv[3]) if len(sys.argv) > 3 else 120)):
+    rng = np.random.default_rng(seed)
+    S = slicer_amd.Slicer(0, max_chunk=int(rng.choice([70000, 100000, 1 << 20])))
+    npix = int(rng.choice([64, 128, 256, 1024]))
+    n_planes = int(rng.integers(1, 5))
+    edges = np.repeat(np.linspace(0.0, 1.0, n_planes + 1), 2)[1:-1]
+    lds = [3.0 + float(e) for e in edges[0::2]]
+    ld2s = [3.0 + float(e) for e in edges[1::2]]
+    if n_planes > 1 and rng.random() < 0.25:
+        ld2s[0] = lds[1] + 0.1      # overlapping slabs: plane groups
+    fov = float(rng.uniform(0.1, 0.25))
+    rnd = dict(sgn=tuple(int(v) for v in rng.choice([-1, 1], 3)), face=int(rng.integers(1, 7)),
+               center=tuple(float(np.float32(v)) if rng.random() < 0.7 else float(v) for v in rng.random(3)), rcase=3.0)
+    files, first = [], 0
+    for _ in range(int(rng.integers(1, 12))):
+        npart = [0] * 6
+        if rng.random() < 0.7:      # one species
+            npart[int(rng.integers(0, 6))] = int(rng.choice([30000, 69999, 70000, 100001, 150000, 210000]))
+        else:
+            for t in rng.choice(6, int(rng.integers(2, 4)), replace=False):
+                npart[int(t)] = int(rng.choice([20000, 70001, 130000]))
+        massarr = [float(rng.uniform(0.01, 3.0)) for _ in range(6)]
+        n = sum(npart)
+        files.append(dict(npart=npart, massarr=massarr, boxsize=T.BOX, pos=T.synth.positions(first, n, T.BOX,
+                                                                                             clustered=rng.random() < 0.5)))
+        first += n
+    types = bool(rng.random() < 0.5)
+    out = T.run_gpu(S, files, npix, fov, lds, ld2s, ngp=True, rnd=rnd, want_type_maps=types)
+    for p in range(n_planes):
+        ref_tot, ref_toti, nsel = T.run_oracle(files, npix, fov, lds[p], ld2s[p], ngp=True, rnd=rnd)
+        ok = np.array_equal(out[p][2], nsel) and np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32))
+        if types:
+            ok = ok and np.array_equal(out[p][1].view(np.uint32), ref_toti.view(np.uint32))
+        if not ok:
+            bad += 1
+            print("FAIL ngp seed", seed, "plane", p, flush=True)
+    S.close()
+print("ngp flavour done, failures:", bad)
