@@ -426,96 +426,147 @@ constexpr int kTileBlock = 1024;
 
 // Deposit this work item's share of every pending chunk into the LDS tile.  CHECK = false for tiles whose halo
 // lies inside the map (all but the border tiles): the per-cell map-edge tests and their exec-mask bookkeeping go.
-template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK>
+struct NoBoundary {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
+
+// boundary(c, c_next) is called when the walk leaves chunk c for chunk c_next (c_end at the very end), after the
+// records of c_next's first round have been requested: the NGP path folds a finished sub-file there.
+template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK, typename Boundary = NoBoundary>
 __device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
                                                 typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                 unsigned nparts, int x0, int y0, int W, unsigned *s_nslow,
-                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, int c_begin, int c_end)
+                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, int c_begin, int c_end,
+                                                Boundary &&boundary = Boundary())
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
     const int nn = P.nn;
-    constexpr int U = 4;  // records in flight per lane
+    constexpr int U = 4;  // records in flight per lane and round
     // (dealing the waves to the pending chunks, so that all runs stream in at once, measured 699 us against 665 us for
     // this chunk-by-chunk walk: the kernel is bound by the LDS atomic pipe, not by the loads)
-    for (int c = c_begin; c < c_end; c++) {
-        // this part's share of the chunk's run: [len*part/nparts, len*(part+1)/nparts)
-        const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
-        const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
-        const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+    // This part's share of each chunk's run, [len*part/nparts, len*(part+1)/nparts): lane c of every wave fetches
+    // chunk c's bounds, so the (<= 8) dependent loads cost one latency instead of one per chunk.
+    unsigned my_start = 0, my_end = 0;
+    {
+        const int c = c_begin + (int)lane_id();
+        if (c < c_end) {
+            const unsigned run0 = L.base[c][bin], len = L.base[c][bin + 1] - run0;
+            my_start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
+            my_end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+        }
+    }
+    auto bounds = [&](int c, unsigned &a, unsigned &b) {
+        a = (unsigned)__builtin_amdgcn_readlane((int)my_start, c - c_begin);
+        b = (unsigned)__builtin_amdgcn_readlane((int)my_end, c - c_begin);
+    };
+    // The walk over (chunk, round of U * kTileBlock records) pairs is software-pipelined: the records of the next
+    // round -- of the next chunk, if this one is exhausted -- are requested before the current round is deposited.
+    auto advance = [&](int &c, unsigned &i0, unsigned &end) {  // -> false when the walk is over
+        i0 += U * kTileBlock;
+        while (i0 >= end) {
+            if (++c >= c_end)
+                return false;
+            bounds(c, i0, end);
+        }
+        return true;
+    };
+    auto fetch = [&](int c, unsigned i0, unsigned end, float2 (&r)[U], float (&mr)[U]) {
         const float2 *__restrict__ sxy = L.sxy[c];
         const float *__restrict__ sm = L.sm[c];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            // clamped, unconditional loads: a load under a branch makes the compiler drain the memory queue
+            // before each one (s_waitcnt vmcnt(0)), which serialises the U loads
+            const unsigned i = i0 + u * kTileBlock + tid;
+            const unsigned ic = i < end ? i : end - 1;
+            r[u] = sxy[ic];
+            if (HAS_MASS)
+                mr[u] = sm[ic];
+        }
+    };
+    int c = c_begin - 1;
+    unsigned i0 = 0, end = 0;
+    bool live = advance(c, i0, end);
+    float2 r[U], rn[U];
+    float mr[U], mn[U];
+    if (live)
+        fetch(c, i0, end, r, mr);
+    while (live) {
+        int cn = c;
+        unsigned in0 = i0, endn = end;
+        const bool more = advance(cn, in0, endn);
+        if (more)
+            fetch(cn, in0, endn, rn, mn);
         const float mconst = L.mconst[c], smc = L.sm_const[c];
-        for (unsigned i0 = start; i0 < end; i0 += U * kTileBlock) {
-            float2 r[U];
-            float mr[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                // clamped, unconditional loads: a load under a branch makes the compiler drain the memory queue
-                // before each one (s_waitcnt vmcnt(0)), which serialises the U loads
-                const unsigned i = i0 + u * kTileBlock + tid;
-                const unsigned ic = i < end ? i : end - 1;
-                r[u] = sxy[ic];
-                if (HAS_MASS)
-                    mr[u] = sm[ic];
+        for (int u = 0; u < U; u++) {
+            const unsigned i = i0 + u * kTileBlock + tid;
+            if (i >= end)
+                continue;
+            const float xs = r[u].x, ys = r[u].y;
+            float m = mconst, sq = smc;
+            if (HAS_MASS) {
+                m = cap_mass(mr[u]);
+                sq = __fsqrt_rn(m);
             }
+            const int gx = grid_index<POW2>(xs, P);
+            const int gy = grid_index<POW2>(ys, P);
+            if (MAS == kNGP) {
+                lds_t *cell = tile + (gy - y0 + 1) * W + (gx - x0 + 1);
+                if (ACC == kCountU32)
+                    atomicAdd(reinterpret_cast<unsigned *>(cell), 1u);
+                else
+                    atomicAdd(reinterpret_cast<double *>(cell), (double)m);
+            } else {
+                float wx[3], wy[3];
+                tsc_axis<POW2>(xs, gx, P, wx);
+                tsc_axis<POW2>(ys, gy, P, wy);
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned i = i0 + u * kTileBlock + tid;
-                if (i >= end)
-                    continue;
-                const float xs = r[u].x, ys = r[u].y;
-                float m = mconst, sq = smc;
-                if (HAS_MASS) {
-                    m = cap_mass(mr[u]);
-                    sq = __fsqrt_rn(m);
+                for (int a = 0; a < 3; a++) {
+                    wx[a] = sq * wx[a];
+                    wy[a] = sq * wy[a];
                 }
-                const int gx = grid_index<POW2>(xs, P);
-                const int gy = grid_index<POW2>(ys, P);
-                if (MAS == kNGP) {
-                    lds_t *cell = tile + (gy - y0 + 1) * W + (gx - x0 + 1);
-                    if (ACC == kCountU32)
-                        atomicAdd(reinterpret_cast<unsigned *>(cell), 1u);
-                    else
-                        atomicAdd(reinterpret_cast<double *>(cell), (double)m);
-                } else {
-                    float wx[3], wy[3];
-                    tsc_axis<POW2>(xs, gx, P, wx);
-                    tsc_axis<POW2>(ys, gy, P, wy);
+                if (kIntCells<ACC>) {
+                    // smallest of the nine products (weights are >= 0; the centre cell holds the largest)
+                    const float cmin = fminf(wx[0], wx[2]) * fminf(wy[0], wy[2]);
+                    if (cmin < P.tile_cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
+                        const unsigned k = atomicAdd(s_nslow, 1u);
+                        if (k < kSlowCap)
+                            s_slow[k] = make_uint2((unsigned)c, i);
+                        else
+                            slow_record<ACC, POW2>(xs, ys, sq, P, tile, gmap, x0, y0, W);
+                        continue;
+                    }
+                }
+                lds_t *cell0 = tile + (gy - y0) * W + (gx - x0);  // cell (gx - 1, gy - 1)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int py = gy + b - 1;
+                    if (CHECK && (py < 0 || py >= nn))
+                        continue;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
-                        wx[a] = sq * wx[a];
-                        wy[a] = sq * wy[a];
-                    }
-                    if (kIntCells<ACC>) {
-                        // smallest of the nine products (weights are >= 0; the centre cell holds the largest)
-                        const float cmin = fminf(wx[0], wx[2]) * fminf(wy[0], wy[2]);
-                        if (cmin < P.tile_cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
-                            const unsigned k = atomicAdd(s_nslow, 1u);
-                            if (k < kSlowCap)
-                                s_slow[k] = make_uint2((unsigned)c, i);
-                            else
-                                slow_record<ACC, POW2>(xs, ys, sq, P, tile, gmap, x0, y0, W);
+                        const int px = gx + a - 1;
+                        if (CHECK && (px < 0 || px >= nn))
                             continue;
-                        }
-                    }
-                    lds_t *cell0 = tile + (gy - y0) * W + (gx - x0);  // cell (gx - 1, gy - 1)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        const int py = gy + b - 1;
-                        if (CHECK && (py < 0 || py >= nn))
-                            continue;
-#pragma unroll
-                        for (int a = 0; a < 3; a++) {
-                            const int px = gx + a - 1;
-                            if (CHECK && (px < 0 || px >= nn))
-                                continue;
-                            lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P);
-                        }
+                        lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P);
                     }
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            r[u] = rn[u];
+            if (HAS_MASS)
+                mr[u] = mn[u];
+        }
+        if (!more || cn != c)
+            boundary(c, more ? cn : c_end);
+        c = cn;
+        i0 = in0;
+        end = endn;
+        live = more;
     }
 }
 
@@ -714,49 +765,52 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         // travel in registers from the first file to the last: lane `tid` owns the tile's cells tid, tid + 1024, ...
         // Any other file's counts go to the global count map.
         constexpr int CPT = 16;  // 128 x 128 cells / 1024 lanes
+        // (the NGP-count instantiations have no per-particle masses; their HAS_MASS flag says instead whether the
+        // species' own map is kept next to the all-types map: 16 more registers per lane, one workgroup per CU less)
+        constexpr bool TYPE_MAP = HAS_MASS;
         float rt[CPT], ri[CPT];
         float *tot = F.tot[plane], *toti = F.toti[plane];
         const int tw = 1 << G.tw_log2, ncell = tw << G.th_log2;
-        auto owned = [&](int j, int &cell, size_t &idx) {  // -> lane's j-th cell lies inside the map
-            const int i = j * kTileBlock + tid;
-            const int row = i >> G.tw_log2, col = i & (tw - 1);
-            cell = (row + 1) * W + col + 1;
-            idx = (size_t)(x0 + col) + (size_t)nn * (size_t)(y0 + row);
-            return i < ncell && x0 + col < nn && y0 + row < nn;
-        };
+        // lane's j-th cell: tile cell i = j * 1024 + tid, i.e. LDS cell cell0 + j * cstride, pixel idx0 + j * pstride
+        const int row0 = tid >> G.tw_log2, col0 = tid & (tw - 1);
+        const int rows_per_j = kTileBlock >> G.tw_log2;  // (tile widths are <= 1024)
+        const int cell0 = (row0 + 1) * W + col0 + 1, cstride = rows_per_j * W;
+        const size_t idx0 = (size_t)(x0 + col0) + (size_t)nn * (size_t)(y0 + row0), pstride = (size_t)nn * (size_t)rows_per_j;
+        unsigned inmask = 0;  // bit j: that cell exists and lies inside the map
+#pragma unroll
+        for (int j = 0; j < CPT; j++)
+            if (j * kTileBlock + tid < ncell && x0 + col0 < nn && y0 + row0 + j * rows_per_j < nn)
+                inmask |= 1u << j;
         if (F.on) {
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
-                int cell;
-                size_t idx;
-                const bool in = owned(j, cell, idx);
-                rt[j] = in ? tot[idx] : 0.0f;
-                ri[j] = (in && toti) ? toti[idx] : 0.0f;
+                const bool in = inmask >> j & 1u;
+                rt[j] = in ? tot[idx0 + j * pstride] : 0.0f;
+                ri[j] = (TYPE_MAP && in && toti) ? toti[idx0 + j * pstride] : 0.0f;
             }
         }
         unsigned touched = 0;
-        for (int c0 = 0; c0 < L.n;) {
-            int c1 = c0 + 1;
-            while (c1 < L.n && L.file_id[c1] == L.file_id[c0])
-                c1++;
-            tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow,
-                                                             gmap, c0, c1);
+        // one walk over all pending chunks; when it leaves the last chunk of a sub-file (the next round's records are
+        // already on their way) the file's counts are folded, or flushed to the count map
+        auto boundary = [&](int c, int c_next) {
+            if (c_next < L.n && L.file_id[c_next] == L.file_id[c])
+                return;
             __syncthreads();
-            if (F.on && L.fold[c0]) {
-                const float m = L.mconst[c0];
+            if (F.on && L.fold[c]) {
+                const float m = L.mconst[c];
+                unsigned kk[CPT];
+#pragma unroll
+                for (int j = 0; j < CPT; j++)  // (all LDS reads first: one latency)
+                    kk[j] = (inmask >> j & 1u) ? (unsigned)tile[cell0 + j * cstride] : 0u;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
-                    int cell;
-                    size_t idx;
-                    if (!owned(j, cell, idx))
+                    if (kk[j] == 0)
                         continue;
-                    const unsigned k = (unsigned)tile[cell];
-                    if (k == 0)
-                        continue;
-                    tile[cell] = (lds_t)0;
-                    const float v = ngp_seq_sum(k, m);
+                    tile[cell0 + j * cstride] = (lds_t)0;
+                    const float v = ngp_seq_sum(kk[j], m);
                     rt[j] = rt[j] + v;  // tot += mapxyi, toti += mapxyi   densitymaps.cpp:511-513
-                    ri[j] = ri[j] + v;
+                    if (TYPE_MAP)
+                        ri[j] = ri[j] + v;
                     touched |= 1u << j;
                 }
             } else {
@@ -770,17 +824,15 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
                 for_each_tile_cell(W, H, flush);
             }
             __syncthreads();
-            c0 = c1;
-        }
+        };
+        tile_accumulate<MAS, ACC, POW2, false, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap, 0,
+                                                      L.n, boundary);
 #pragma unroll
         for (int j = 0; j < CPT; j++)
             if (touched >> j & 1u) {
-                int cell;
-                size_t idx;
-                (void)owned(j, cell, idx);
-                tot[idx] = rt[j];
-                if (toti)
-                    toti[idx] = ri[j];
+                tot[idx0 + j * pstride] = rt[j];
+                if (TYPE_MAP && toti)
+                    toti[idx0 + j * pstride] = ri[j];
             }
         return;
     }
@@ -924,7 +976,8 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
     const bool pow2 = P.pow2 != 0;
     if (cfg.mas == kNGP) {
         if (cfg.acc == kCountU32) {
-            return launch_k4<kNGP, kCountU32>(pow2, false, P, G, L, T, I, F, max_items, s);
+            // (has_mass slot of the count kernels: keep the species' own map in the in-tile fold)
+            return launch_k4<kNGP, kCountU32>(pow2, F.on && F.toti[0] != nullptr, P, G, L, T, I, F, max_items, s);
         }
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }
