@@ -290,9 +290,12 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
                 const unsigned hi = nsub - lo < (unsigned)kSortStage ? nsub - lo : (unsigned)kSortStage;
                 for (unsigned q = tid; q < hi; q += kSortBlock) {
                     const unsigned dst = cur[sorted_tile[q]] + lo + q;
-                    sxy[dst] = sorted_xy[q];
-                    if (HAS_MASS)
-                        sm[dst] = sorted_m[q];
+                    if (HAS_MASS) {  // one 12-byte record instead of an 8-byte and a 4-byte stream
+                        const float2 v = sorted_xy[q];
+                        reinterpret_cast<Rec3 *>(sxy)[dst] = Rec3{v.x, v.y, sorted_m[q]};
+                    } else {
+                        sxy[dst] = sorted_xy[q];
+                    }
                 }
             }
             if (!single) {
@@ -442,7 +445,10 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
     const int nn = P.nn;
-    constexpr int U = 4;  // records in flight per lane and round
+#ifndef SLICER_K4_U
+#define SLICER_K4_U 4
+#endif
+    constexpr int U = SLICER_K4_U;  // records in flight per lane and round
     // (dealing the waves to the pending chunks, so that all runs stream in at once, measured 699 us against 665 us for
     // this chunk-by-chunk walk: the kernel is bound by the LDS atomic pipe, not by the loads)
     // This part's share of each chunk's run, [len*part/nparts, len*(part+1)/nparts): lane c of every wave fetches
@@ -473,16 +479,19 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     };
     auto fetch = [&](int c, unsigned i0, unsigned end, float2 (&r)[U], float (&mr)[U]) {
         const float2 *__restrict__ sxy = L.sxy[c];
-        const float *__restrict__ sm = L.sm[c];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             // clamped, unconditional loads: a load under a branch makes the compiler drain the memory queue
             // before each one (s_waitcnt vmcnt(0)), which serialises the U loads
             const unsigned i = i0 + u * kTileBlock + tid;
             const unsigned ic = i < end ? i : end - 1;
-            r[u] = sxy[ic];
-            if (HAS_MASS)
-                mr[u] = sm[ic];
+            if (HAS_MASS) {
+                const Rec3 v = reinterpret_cast<const Rec3 *>(sxy)[ic];
+                r[u] = make_float2(v.x, v.y);
+                mr[u] = v.m;
+            } else {
+                r[u] = sxy[ic];
+            }
         }
     };
     int c = c_begin - 1;
@@ -614,16 +623,21 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
         const unsigned start = run0 + (unsigned)(((unsigned long long)len * part) / nparts);
         const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
         const float2 *__restrict__ sxy = L.sxy[c];
-        const float *__restrict__ sm = L.sm[c];
         // every lane of the workgroup runs every iteration (no divergent exit: the butterfly needs all lanes)
         for (unsigned i0 = start; i0 < end; i0 += kTileBlock) {
             const unsigned i = i0 + tid;
             const bool act = i < end;
-            const float2 r = act ? sxy[i] : make_float2(0.f, 0.f);
+            float2 r = make_float2(0.f, 0.f);
             float m = L.mconst[c], sq = L.sm_const[c];
             if (HAS_MASS) {
-                m = act ? cap_mass(sm[i]) : 0.f;
+                Rec3 v{0.f, 0.f, 0.f};
+                if (act)
+                    v = reinterpret_cast<const Rec3 *>(sxy)[i];
+                r = make_float2(v.x, v.y);
+                m = cap_mass(v.m);
                 sq = __fsqrt_rn(m);
+            } else if (act) {
+                r = sxy[i];
             }
             const int gx = grid_index<POW2>(r.x, P), gy = grid_index<POW2>(r.y, P);
             const int cell = act ? (gy - y0) * W + (gx - x0) : -1;  // cell (gx - 1, gy - 1) of the halo'd tile

@@ -28,6 +28,12 @@ __device__ __forceinline__ void lds_barrier()
 // LDS traffic of this wave is complete and the compiler may not move memory operations across
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Sorted record of the per-particle-mass (hydro) path: (xs, ys, m) in one 12-byte store / load.  The constant-mass path
+// keeps 8-byte float2 records; PendingList::sxy points at one or the other (sm != nullptr tells which).
+struct __attribute__((packed, aligned(4))) Rec3 {
+    float x, y, m;
+};
+
 // (unit, tile-in-unit) of a map cell under the tile geometry G.  A unit is a plane, or a band of rows_per_unit tile
 // rows of a plane on large maps (BinGeom).
 __device__ __forceinline__ void cell_to_tile(int gx, int gy, int plane, const BinGeom &G, unsigned &unit,

@@ -113,7 +113,7 @@ struct slicer_handle_s {
         BinGeom G{};
         Targets T{};
         uint64_t particles = 0;  // particles behind the pending chunks (bounds their record count)
-        DevBuf w_sxy[kMaxPending], w_sm[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
+        DevBuf w_sxy[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
     };
     Pending pg[SLICER_MAX_PLANES];
 
@@ -622,16 +622,16 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int group, int slot, ui
         (rc = ensure(h, h->w_hist, nb * (uint64_t)G.nbins * 4)) ||
         (rc = ensure(h, h->w_hist16, nb * (uint64_t)(G.nbins + 2) * 2)) ||
         (rc = ensure(h, h->w_total, (kMaxBins + kMaxBins / 32 + 1) * 4)) ||
-        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, Q.w_sxy[slot], nrec * 8)) ||
+        (rc = ensure(h, h->w_bcount, nb * kMaxUnits * 4)) || (rc = ensure(h, Q.w_sxy[slot], nrec * (has_mass ? 12 : 8))) ||  // float2, or Rec3 with per-particle masses
         (rc = ensure(h, Q.w_base[slot], (kMaxBins + 1) * 4)))
         return rc;
-    if (has_mass && ((rc = ensure(h, h->w_cm, region * 4)) || (rc = ensure(h, Q.w_sm[slot], nrec * 4))))
+    if (has_mass && (rc = ensure(h, h->w_cm, region * 4)))
         return rc;
     W.cxy = (float2 *)h->w_cxy.p;
     W.cbin = (unsigned short *)h->w_cbin.p;
     W.cm = (float *)h->w_cm.p;
     W.sxy = (float2 *)Q.w_sxy[slot].p;
-    W.sm = (float *)Q.w_sm[slot].p;
+    W.sm = has_mass ? (float *)Q.w_sxy[slot].p : nullptr;  // (the masses travel inside the 12-byte sorted records)
     W.hist = (unsigned *)h->w_hist.p;
     W.hist16 = (unsigned *)h->w_hist16.p;
     W.total = (unsigned *)h->w_total.p;
@@ -1146,7 +1146,6 @@ int slicer_destroy(slicer_handle h)
     for (auto &Q : h->pg)
         for (int i = 0; i < kMaxPending; i++) {
             release(Q.w_sxy[i]);
-            release(Q.w_sm[i]);
             release(Q.w_base[i]);
         }
     for (int i = 0; i < 2; i++) {

@@ -91,7 +91,7 @@ struct BinWorkspace {
     unsigned short *cbin;  // same shape: tile-in-unit of each compact record (K3 sorts by it)
     float *cm;         // same shape: per-particle mass (hydro) or nullptr
     float2 *sxy;       // [max_chunk] records grouped by bin
-    float *sm;         // [max_chunk] or nullptr
+    float *sm;         // non-null with per-particle masses: sxy then holds 12-byte (xs, ys, m) records
     unsigned *hist16;  // [nblocks][ceil(nbins/2)] per-workgroup histogram, two u16 counters per word
     unsigned *hist;    // [nblocks][nbins] exclusive prefix over workgroups (write cursors)
     unsigned *total;   // [nbins] exclusive prefix of the bin totals inside each group of kScanBins bins | [ngroups] group sums
@@ -156,7 +156,7 @@ constexpr int kMaxPending = SLICER_MAX_PENDING;
 struct PendingList {
     int n;
     const float2 *sxy[kMaxPending];
-    const float *sm[kMaxPending];
+    const float *sm[kMaxPending];  // non-null: the chunk's sxy holds 12-byte (xs, ys, m) records (Rec3)
     const unsigned *base[kMaxPending];
     float mconst[kMaxPending];    // (float)massarr[t] of the chunk's file
     float sm_const[kMaxPending];  // sqrtf(mconst)
