@@ -996,12 +996,13 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }
     // constant-mass TSC in the F32 / F64 modes: integer tile cells (SLICER_K4_INT=0 keeps the f64 cells, =2 forces the
-    // integer ones).  They pay where the records dominate; a launch with few records per tile (large maps: 8192^2 x 4
-    // planes has ~3000) is mostly tile zeroing and flushing, where the u64 -> float conversion of every cell costs
-    // more than the cheaper LDS atomic saves (1429 against 1221 us there).
+    // integer ones).  They pay where the records dominate (2048^2 x 4 planes, 65536 particles per bin: 370 against 622 us);
+    // a launch with few records per tile is mostly tile zeroing and flushing, where the u64 -> float conversion of every
+    // cell costs what the cheaper LDS atomic saves (8192^2 x 4 planes, 4096 per bin: 1242 against 1205 us; 2048 per bin:
+    // equal) -- below 2048 particles per bin the f64 cells stay.
     const char *env_int = getenv("SLICER_K4_INT");
     const int int_mode = env_int ? atoi(env_int) : 1;
-    const bool int_cells = int_mode == 2 || (int_mode == 1 && total_particles / (uint64_t)G.nbins >= 8192);
+    const bool int_cells = int_mode == 2 || (int_mode == 1 && total_particles / (uint64_t)G.nbins >= 2048);
     if (int_cells && !cfg.has_mass && (cfg.acc == kF32 || cfg.acc == kF64)) {
         bool same_mass = true;  // one quantum per launch: all pending chunks carry the same constant mass
         for (int c = 1; c < L.n; c++)

@@ -67,8 +67,8 @@ def headline_ref():
 
 @pytest.mark.parametrize("accum", ["f32", "f64", "fixed64"])
 def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum, monkeypatch):
-    # one sub-file alone has 2048 particles per (plane, tile) bin; the benchmark flushes eight at once (16384 per bin) and
-    # therefore keeps integer tile cells in the F32 / F64 modes: force that kernel here
+    # the benchmark keeps integer tile cells in the F32 / F64 modes (16384 particles per (plane, tile) bin and launch; one
+    # sub-file alone sits right at the 2048 threshold): force that kernel here
     monkeypatch.setenv("SLICER_K4_INT", "2")
     pos, ref = headline_ref
     n = len(pos)
