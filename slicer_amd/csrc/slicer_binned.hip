@@ -4,19 +4,20 @@
 // ~0.08 TB/s of added bytes on MI355X (64 lanes in 64 rows; MI355X_MICROARCH.md "Global float
 // atomics"), i.e. ~2e9 particles/s.  Here the scatter is done in LDS instead:
 //
-//   K1 k_project_bin   : stream raw POS (12 B/particle, dwordx4 loads), bit-faithful transform, slab
-//                        select; survivors are compacted through an LDS queue so that the fp64
-//                        sqrt/asin/atan2 run on full waves; emits (xs, ys) records + their tile bin,
-//                        a per-block histogram row and the block's record count.  No global atomics
-//                        on the data path.
-//   K2 k_scan_blocks / k_scan_bins : exclusive prefix over (bin-major, block-minor) -> every block's
-//                        write cursor for every bin (radix-partition style; no atomics).
+//   K1 k_project_bin_* : (slicer_project_bin.hip) stream raw POS (12 B/particle, dwordx4 loads), bit-faithful
+//                        transform, slab select, fp64 projection; emits (xs, ys) records + their tile bin, a
+//                        per-workgroup histogram row and the workgroup's record counts.  No global atomics on the
+//                        data path.
+//   K2 k_scan_blocks   : exclusive prefix over (bin-major, workgroup-minor) -> every K1 workgroup's write cursor for
+//                        every bin (radix-partition style; no atomics), plus in-group bin prefixes and group sums
+//                        from which K3 derives the bin bases itself.
 //   K3 k_bin_scatter   : moves each record to its bin's contiguous run: persistent workgroups counting-sort
 //                        the records of one (plane, K1 workgroup) region by tile in LDS and store them in
 //                        tile order (coalesced runs).
 //   K4 k_tile_deposit  : one workgroup per (plane, tile) (more for heavy tiles): tile + 1-pixel halo
-//                        privatised in LDS as 8-byte cells, ds_add_{f64,u64,u32} per contribution, then one
-//                        shaped (row-contiguous) global atomic flush of the non-zero cells.
+//                        privatised in LDS as 8-byte cells (f64 or integer) or 4-byte NGP counts, one software-pipelined
+//                        walk over all pending chunks, then one shaped (row-contiguous) flush of the non-zero cells;
+//                        NGP counts of whole sub-files are folded into the f32 maps at the file boundaries of the walk.
 //
 // Replaces the CPU loops of gadget2io.cpp:195-274, densitymaps.cpp:355-401 and utilities.cpp:66-95.
 #include "slicer_binned_common.hpp"
