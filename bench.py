@@ -572,7 +572,20 @@ def end_to_end(a):
         if r.returncode or len(ms) < 2:
             return {"error": f"adapter_driver rc={r.returncode}"}
         best = min(ms[1:])
+        # the same sub-file for the four planes of one box replication, called plane by plane as slicer-v2.cpp does: the
+        # adapter deposits all four during the first call and serves the other three from the device
+        four = None
+        env4 = dict(os.environ, ADAPTER_REPEAT="3", SLICER_AMD_READ_THREADS="8")
+        r4 = subprocess.run([drv, base, "0", "1", str(a.npix), str(FOV), "3.0,3.25,3.5,3.75", "3.25,3.5,3.75,4.0", "3.0", "0",
+                             "0", os.path.join(d, "m4.bin")], capture_output=True, env=env4, text=True, timeout=300)
+        ms4 = [float(ln.split(": ")[1].split()[0]) for ln in r4.stderr.splitlines() if ln.startswith("createDensityMaps call")]
+        if r4.returncode == 0 and len(ms4) == 12:
+            loops = [ms4[4 * k:4 * k + 4] for k in range(1, 3)]
+            bl = min(loops, key=sum)
+            four = {"calls_ms": bl, "ms_per_plane": sum(bl) / 4.0, "input_particles_per_s_per_plane": n / (sum(bl) / 4.0 * 1e-3),
+                    "what": "four createDensityMaps calls (planes of one replication) on the same sub-file; best of 2 warm loops"}
         return {"value": n / (best * 1e-3), "unit": "input particles/s", "ms_per_call": best, "calls_ms": ms,
+                "four_planes": four,
                 "pcie_frac": 12.0 * n / (best * 1e-3) / PCIE_PEAK,
                 "what": f"page-cached format-2 file ({n} particles) -> C++ createDensityMaps (one plane, {a.npix}^2 TSC) -> "
                         "all-types map + populated per-type map in host memory; 8 read threads; best of 4 warm calls"}

@@ -15,11 +15,28 @@
 
 namespace {
 
+// The planes the last pass produced besides the one it was asked for.  slicer-v2.cpp calls createDensityMaps once per
+// lens plane, and the planes of one box replication (lens.randomize set on the first only) read the same sub-files with
+// the same Random entry and rcase: the adapter deposits them all in the pass of the first call (one file read, one H2D
+// copy, one run of the kernels for up to SLICER_MAX_PLANES planes) and leaves the others on the device, where the
+// following calls pick them up.  Every entry serves one call; any other call starts a fresh pass.
+struct PlaneGroup {
+    bool valid = false;
+    int first = 0, n = 0;
+    bool used[SLICER_MAX_PLANES] = {};
+    std::string file;
+    unsigned ffmin = 0, ffmax = 0;
+    double fov = 0;
+    float rcase = 0;
+    int npix = 0, hydro = 0, mas = 0, accum = 0;
+};
+
 struct AdapterState {
     slicer_handle h = nullptr;
     int device = -1;
     int mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32, algo = SLICER_ALGO_AUTO, true_counts = 0;
     int want_device = -1;
+    PlaneGroup grp;
 };
 AdapterState g;
 
@@ -68,6 +85,7 @@ extern "C" void slicer_amd_adapter_shutdown(void)
     if (g.h)
         slicer_destroy(g.h);
     g.h = nullptr;
+    g.grp.valid = false;
 }
 
 int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, unsigned int ffmin, unsigned int ffmax,
@@ -107,25 +125,70 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
         return 1;
     slicer_handle h = g.h;
 
-    slicer_plane_desc d{};
-    d.npix = p.npix;
-    d.n_planes = 1;
-    d.mas = g.mas;
-    d.accum = g.accum;
-    d.algo = g.algo;
-    d.hydro = p.hydro ? 1 : 0;
-    d.snopt = p.snopt;
-    d.want_type_maps = 1;
-    d.fov_rad = fovradiants;
-    d.ld[0] = lens.ld[isnap];
-    d.ld2[0] = lens.ld2[isnap];
-    d.nrepperp[0] = lens.nrepperp[isnap];
-    if (slicer_plane_begin(h, &d) != SLICER_OK) {
-        std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
-        return 1;
+    // a plane left on the device by the pass of an earlier call (see PlaneGroup)?
+    PlaneGroup &G = g.grp;
+    int slot = 0;
+    bool made_group = false;
+    const bool hit = G.valid && isnap > G.first && isnap < G.first + G.n && !G.used[isnap - G.first] && G.file == File &&
+                     G.ffmin == ffmin && G.ffmax == ffmax && G.fov == fovradiants && G.rcase == (float)rcase &&
+                     G.npix == p.npix && G.hydro == (p.hydro ? 1 : 0) && G.mas == g.mas && G.accum == g.accum;
+    if (hit) {
+        slot = isnap - G.first;
+        G.used[slot] = true;
+    } else {
+        G.valid = false;
+        // planes that follow in the same box replication: same snapshot, same Random entry, no new randomisation
+        // (slicer-v2.cpp:184-185 keeps rcase for them).  SLICER_AMD_LOOKAHEAD=0 restores one plane per pass.
+        int n = 1;
+        auto same = [&](int j) {
+            const size_t k = (size_t)j, i = (size_t)isnap;
+            return k < lens.randomize.size() && k < lens.fromsnap.size() && k < lens.ld.size() && k < lens.ld2.size() &&
+                   k < lens.nrepperp.size() && k < random.x0.size() && k < random.face.size() && !lens.randomize[k] &&
+                   lens.fromsnap[k] == lens.fromsnap[i] && random.x0[k] == random.x0[i] && random.y0[k] == random.y0[i] &&
+                   random.z0[k] == random.z0[i] && random.face[k] == random.face[i] && random.sgnX[k] == random.sgnX[i] &&
+                   random.sgnY[k] == random.sgnY[i] && random.sgnZ[k] == random.sgnZ[i];
+        };
+        if (env_int("SLICER_AMD_LOOKAHEAD", 1) && p.snopt == 0 && !p.physical && isnap < (int)lens.fromsnap.size())
+            while (n < SLICER_MAX_PLANES && isnap + n < lens.nplanes && same(isnap + n))
+                n++;
+        slicer_plane_desc d{};
+        d.npix = p.npix;
+        d.n_planes = n;
+        d.mas = g.mas;
+        d.accum = g.accum;
+        d.algo = g.algo;
+        d.hydro = p.hydro ? 1 : 0;
+        d.snopt = p.snopt;
+        d.want_type_maps = 1;
+        d.fov_rad = fovradiants;
+        for (int j = 0; j < n; j++) {
+            d.ld[j] = lens.ld[isnap + j];
+            d.ld2[j] = lens.ld2[isnap + j];
+            d.nrepperp[j] = lens.nrepperp[isnap + j];
+        }
+        if (slicer_plane_begin(h, &d) != SLICER_OK) {
+            std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
+            return 1;
+        }
+        if (n > 1) {
+            made_group = true;
+            G.first = isnap;
+            G.n = n;
+            for (int j = 0; j < SLICER_MAX_PLANES; j++)
+                G.used[j] = j == 0;
+            G.file = File;
+            G.ffmin = ffmin;
+            G.ffmax = ffmax;
+            G.fov = fovradiants;
+            G.rcase = (float)rcase;
+            G.npix = p.npix;
+            G.hydro = p.hydro ? 1 : 0;
+            G.mas = g.mas;
+            G.accum = g.accum;
+        }
     }
 
-    for (unsigned int ff = ffmin; ff < ffmax; ff++) {
+    for (unsigned int ff = ffmin; ff < ffmax && !hit; ff++) {
         char suffix[32];
         snprintf(suffix, sizeof suffix, "%i", (int)ff);  // sconv(ff, fINT)
         const std::string file_in = File + "." + suffix;
@@ -208,7 +271,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
     // all-types map and counters, then every per-type map straight from the device into the caller's array (types
     // that never appeared have no device map: zeros)
     int64_t nsel[6] = {0, 0, 0, 0, 0, 0};
-    int rc = slicer_plane_read(h, 0, &mapxytot[0], nullptr, nsel);
+    int rc = slicer_plane_read(h, slot, &mapxytot[0], nullptr, nsel);
     if (rc != SLICER_OK) {
         std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
         if (rc == SLICER_ERR_NEGATIVE_COORD)
@@ -216,7 +279,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
         return 1;
     }
     float *d_toti[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (slicer_plane_device_maps(h, 0, nullptr, d_toti) != SLICER_OK) {
+    if (slicer_plane_device_maps(h, slot, nullptr, d_toti) != SLICER_OK) {
         std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
         return 1;
     }
@@ -229,6 +292,8 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
         }
         ntotxyi[i] = g.true_counts ? (int)nsel[i] : 0;
     }
+    if (made_group)
+        G.valid = true;  // the pass went through: its other planes wait on the device
     if (myid == 0)
         std::cout << " maps done! from Rank:" << myid << std::endl;
     return 0;

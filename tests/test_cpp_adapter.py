@@ -68,3 +68,32 @@ def test_adapter_matches_oracle(tmp_path, hydro):
     # a missing sub-file makes createDensityMaps return 1, as readHeader's failure does (densitymaps.cpp:438)
     r = run_driver(base, 0, 3, npix, fov, ld, ld2, rcase, 1, hydro, str(tmp_path / "x.bin"))
     assert r.returncode == 1 and "Error in opening the file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_deposits_the_planes_of_one_replication_in_one_pass(tmp_path):
+    """slicer-v2.cpp calls createDensityMaps once per plane; the planes of one box replication share sub-files, Random
+    entry and rcase, so the adapter deposits them all during the first call and serves the others from the device.
+    Every plane must come out as if it had its own pass: bit for bit (NGP), and identical bytes with the look-ahead off."""
+    npix, fov, rcase = 64, 0.25, 3.0
+    lds, ld2s = [3.0, 3.3, 3.7], [3.3, 3.7, 4.0]
+    base, files = make_files(tmp_path, False)
+    per_plane = 7 * npix * npix * 4 + 6 * 4
+    outs = {}
+    for look in ("1", "0"):
+        out = str(tmp_path / f"planes_{look}.bin")
+        env = dict(os.environ, SLICER_AMD_LOOKAHEAD=look, ADAPTER_TIMES="1")
+        r = subprocess.run([DRIVER, base, "0", "2", str(npix), repr(fov), ",".join(map(repr, lds)), ",".join(map(repr, ld2s)),
+                            repr(rcase), "1", "0", out], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[look] = open(out, "rb").read()
+        assert len(outs[look]) == 3 * per_plane
+        assert r.stderr.count("createDensityMaps call") == 3
+    assert outs["1"] == outs["0"]
+    for p in range(3):
+        raw = np.frombuffer(outs["1"], np.float32, 7 * npix * npix, offset=p * per_plane).reshape(7, npix, npix)
+        rc, tot, toti, nsel = oracle.create_density_maps(files, 0, 2, npix, False, True, lds[p], ld2s[p], 0, fov,
+                                                         (-1, 1, -1), 3, (0.3, 0.6, 0.1), rcase)
+        assert rc == 0 and nsel.sum() > 0
+        assert np.array_equal(raw[0].view(np.uint32), tot.view(np.uint32))
+        assert np.array_equal(raw[1:].view(np.uint32), toti.view(np.uint32))
