@@ -1037,3 +1037,32 @@ def test_ngp_file_with_a_binned_and_a_tiny_chunk():
                     assert np.array_equal(out[p][1].view(np.uint32), ref_toti.view(np.uint32))
     finally:
         S2.close()
+
+
+@pytest.mark.parametrize("ngp", [True, False])
+def test_eight_planes_in_one_pass(S, ngp):
+    """SLICER_MAX_PLANES slabs in one pass (the fast project+bin kernel serves up to four: this is the general kernel's
+    case), two files with two species each, binned, against the oracle plane by plane."""
+    edges = [3.0 + 0.125 * k for k in range(9)]
+    lds, ld2s = edges[:-1], edges[1:]
+    files, first = [], 0
+    for ff in range(2):
+        npart = [0, 120001 + ff, 0, 0, 40001, 0]
+        n = sum(npart)
+        files.append(dict(npart=npart, massarr=[0, 0.0123, 0, 0, 0.3, 0], boxsize=BOX, pos=synth.positions(first, n, BOX)))
+        first += n
+    rnd = dict(RND, center=tuple(float(np.float32(c)) for c in RND["center"]))
+    npix = 256
+    out = run_gpu(S, files, npix, 0.25, lds, ld2s, ngp=ngp, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED and S.algo_mask() & 32
+    for p in range(8):
+        ref_tot, ref_toti, nsel = run_oracle(files, npix, 0.25, lds[p], ld2s[p], ngp=ngp, rnd=rnd)
+        tot, toti, cnt = out[p]
+        assert np.array_equal(cnt, nsel) and nsel.sum() > 0
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+            assert np.array_equal(toti.view(np.uint32), ref_toti.view(np.uint32))
+        else:
+            assert np.array_equal(tot == 0, ref_tot == 0)
+            d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+            assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
