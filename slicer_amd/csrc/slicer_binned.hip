@@ -195,6 +195,10 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
     const int per = (tpp + kSortBlock - 1) / kSortBlock;  // tiles per lane in the scan (<= 8)
     auto get16 = [](const unsigned *tab, unsigned t) { return (tab[t >> 1] >> ((t & 1u) * 16u)) & 0xFFFFu; };
     constexpr int R = kSortBatch / kSortBlock;  // records per lane and sub-batch
+    // largest selected mass of the species (as the deposit sees it: above MAX_M counts as 0) -> the quantum of integer
+    // tile cells (TileQuantum); masses are non-negative, so their bits order like the values.  One atomic per wave and
+    // launch, and only if it can raise the maximum.
+    float mass_max = 0.0f;
     for (int item = blockIdx.x; item < G.n_units * per_unit; item += gridDim.x) {
         const int plane = item / per_unit;  // the unit index (a whole plane unless the map is large)
         const int u = item % per_unit;
@@ -273,6 +277,12 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
                 else
                     tile[k] = 0xFFFF0000u;  // position 65535: outside every staging round
             }
+            if (HAS_MASS) {
+#pragma unroll
+                for (int k = 0; k < R; k++)
+                    if ((unsigned)k * kSortBlock + tid < nsub)
+                        mass_max = fmaxf(mass_max, cap_mass(m[k]));
+            }
             // exchange through LDS and write out, kSortStage sorted positions at a time (the staging area is what
             // limits the workgroups per CU)
             for (unsigned lo = 0; lo < nsub; lo += kSortStage) {
@@ -307,6 +317,13 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
             }
         }
     }
+    if (HAS_MASS) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+            mass_max = fmaxf(mass_max, __shfl_xor(mass_max, d));
+        if (lane_id() == 0 && __float_as_uint(mass_max) > *T.max_mass)
+            atomicMax(T.max_mass, __float_as_uint(mass_max));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,21 +350,29 @@ template <int ACC> constexpr bool kIntCells = ACC == kF32I || ACC == kF64I;
 // list, treated after the loop (slow_record); the loop itself stays branch-free.
 constexpr unsigned kSlowCap = 1024;  // noted records per work item (<= 16384 records: 1 % are ~160)
 
+// The quantum of an integer-cell tile: 2^(le - 49) with 2^le above the (largest) particle mass of the launch.  With one
+// constant mass it comes from the pass parameters; with per-particle masses from the largest selected mass the sort
+// kernel has seen for the species (Targets::max_mass), read when the tile kernel starts.
+struct TileQuantum {
+    double scale, inv_scale;  // 2^(49 - le), 2^(le - 49)
+    float cmin;               // 2^(le - 25): every contribution >= this is an exact multiple of the quantum
+};
+
 template <int ACC>
-__device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, const PassParams &P)
+__device__ __forceinline__ void lds_add(typename AccT<ACC>::lds *cell, float c, const PassParams &P, const TileQuantum &Q)
 {
     if (ACC == kF32 || ACC == kF64)
         atomicAdd(reinterpret_cast<double *>(cell), (double)c);  // ds_add_f64
     else if (ACC == kFixed64)
         atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, P.fixed_scale));  // ds_add_u64
     else if (kIntCells<ACC>)
-        atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, P.tile_scale));
+        atomicAdd(reinterpret_cast<unsigned long long *>(cell), rn_scaled_u64(c, Q.scale));
 }
 
 // One record of an integer-cell tile with the representability test per contribution: exact ones into the tile, the
 // others straight to the global accumulator map (gmap, acc_t = float or double).
 template <int ACC, bool POW2>
-__device__ __forceinline__ void slow_record(float xs, float ys, float sq, const PassParams &P,
+__device__ __forceinline__ void slow_record(float xs, float ys, float sq, const PassParams &P, const TileQuantum &Q,
                                             typename AccT<ACC>::lds *tile, typename AccT<ACC>::type *gmap, int x0, int y0,
                                             int W)
 {
@@ -367,7 +392,7 @@ __device__ __forceinline__ void slow_record(float xs, float ys, float sq, const 
             if (px < 0 || px >= nn || py < 0 || py >= nn)
                 continue;
             const float c = wx[a] * wy[b];
-            const double t = (double)c * P.tile_scale;
+            const double t = (double)c * Q.scale;
             if (t == rint(t))
                 atomicAdd(reinterpret_cast<unsigned long long *>(tile + (gy - y0 + b) * W + (gx - x0 + a)),
                           (unsigned long long)t);
@@ -440,8 +465,8 @@ template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK, typename Bound
 __device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
                                                 typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                 unsigned nparts, int x0, int y0, int W, unsigned *s_nslow,
-                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, int c_begin, int c_end,
-                                                Boundary &&boundary = Boundary())
+                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, const TileQuantum &Q,
+                                                int c_begin, int c_end, Boundary &&boundary = Boundary())
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
@@ -539,13 +564,15 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
                 }
                 if (kIntCells<ACC>) {
                     // smallest of the nine products (weights are >= 0; the centre cell holds the largest)
+                    if (HAS_MASS && m == 0.0f)
+                        continue;  // (a mass above MAX_M counts as 0: nine additions of +0)
                     const float cmin = fminf(wx[0], wx[2]) * fminf(wy[0], wy[2]);
-                    if (cmin < P.tile_cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
+                    if (cmin < Q.cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
                         const unsigned k = atomicAdd(s_nslow, 1u);
                         if (k < kSlowCap)
                             s_slow[k] = make_uint2((unsigned)c, i);
                         else
-                            slow_record<ACC, POW2>(xs, ys, sq, P, tile, gmap, x0, y0, W);
+                            slow_record<ACC, POW2>(xs, ys, sq, P, Q, tile, gmap, x0, y0, W);
                         continue;
                     }
                 }
@@ -560,7 +587,7 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
                         const int px = gx + a - 1;
                         if (CHECK && (px < 0 || px >= nn))
                             continue;
-                        lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P);
+                        lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P, Q);
                     }
                 }
             }
@@ -614,7 +641,7 @@ template <int MAS, int ACC, bool POW2, bool HAS_MASS>
 __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, const PassParams &P,
                                                        typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                        unsigned nparts, int x0, int y0, int W,
-                                                       typename AccT<ACC>::type *gmap)
+                                                       typename AccT<ACC>::type *gmap, const TileQuantum &Q)
 {
     using lds_t = typename AccT<ACC>::lds;
     const int tid = threadIdx.x;
@@ -686,7 +713,7 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
                     bool in = act && px >= 0 && px < nn && py >= 0 && py < nn;
                     const float cf = wx[a] * wy[b];
                     if (kIntCells<ACC>) {  // contributions that are no multiple of the tile's quantum bypass the tile
-                        const double t = (double)cf * P.tile_scale;
+                        const double t = (double)cf * Q.scale;
                         if (in && t != rint(t)) {
                             atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (typename AccT<ACC>::type)cf);
                             in = false;
@@ -694,7 +721,7 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
                     }
                     if (uniform) {  // wave-uniform branch
                         if (kIntCells<ACC>) {
-                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, P.tile_scale) : 0ull);
+                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, Q.scale) : 0ull);
                             if ((int)lane_id() == lead && tot)
                                 atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
                         } else if (ACC == kFixed64) {
@@ -707,7 +734,7 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
                                 atomicAdd(reinterpret_cast<double *>(tile + cell0 + b * W + a), tot);
                         }
                     } else if (in) {
-                        lds_add<ACC>(tile + cell + b * W + a, cf, P);
+                        lds_add<ACC>(tile + cell + b * W + a, cf, P, Q);
                     }
                 }
             }
@@ -765,6 +792,15 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     unsigned &s_nslow = *reinterpret_cast<unsigned *>(tile + cells);
     uint2 *s_slow = reinterpret_cast<uint2 *>(tile + cells) + 1;  // [kSlowCap] {chunk, record}: integer-cell modes only
     acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
+    TileQuantum Q{P.tile_scale, P.tile_inv_scale, P.tile_cmin};
+    if (kIntCells<ACC> && HAS_MASS) {
+        // per-particle masses: the scale follows the largest selected mass of the species (bits of a non-negative f32)
+        const unsigned mm = *T.max_mass;
+        const int le = mm ? (int)((mm >> 23) & 0xFFu) - 126 : 0;  // 2^le > m for every m <= that maximum
+        Q.scale = __builtin_ldexp(1.0, 49 - le);
+        Q.inv_scale = __builtin_ldexp(1.0, le - 49);
+        Q.cmin = __builtin_ldexpf(1.0f, le - 25);
+    }
     for (int i = tid; i < cells; i += kTileBlock)
         tile[i] = (lds_t)0;
     if (tid == 0)
@@ -840,7 +876,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
             }
             __syncthreads();
         };
-        tile_accumulate<MAS, ACC, POW2, false, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap, 0,
+        tile_accumulate<MAS, ACC, POW2, false, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap, Q, 0,
                                                       L.n, boundary);
 #pragma unroll
         for (int j = 0; j < CPT; j++)
@@ -854,13 +890,13 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     // pre-reduction only for bins far beyond a tile's usual load (>= 8 parts = 131072 records: a halo core); a bin that
     // is merely split in two or three is faster through the plain loop (--clustered: 810 us with, 700 us without)
     if (nparts >= kMergeParts)
-        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap);
+        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap, Q);
     else if (MAS == kNGP || interior)
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
-                                                         0, L.n);
+                                                         Q, 0, L.n);
     else
         tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
-                                                        0, L.n);
+                                                        Q, 0, L.n);
     __syncthreads();
     if (kIntCells<ACC>) {
         // the records noted in the loop: those of their contributions that are exact multiples of the quantum go into
@@ -868,8 +904,13 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         const unsigned ns = s_nslow < kSlowCap ? s_nslow : kSlowCap;
         for (unsigned e = tid; e < ns; e += kTileBlock) {
             const uint2 w = s_slow[e];
-            const float2 r = L.sxy[w.x][w.y];
-            slow_record<ACC, POW2>(r.x, r.y, L.sm_const[w.x], P, tile, gmap, x0, y0, W);
+            if (HAS_MASS) {
+                const Rec3 r = reinterpret_cast<const Rec3 *>(L.sxy[w.x])[w.y];
+                slow_record<ACC, POW2>(r.x, r.y, __fsqrt_rn(cap_mass(r.m)), P, Q, tile, gmap, x0, y0, W);
+            } else {
+                const float2 r = L.sxy[w.x][w.y];
+                slow_record<ACC, POW2>(r.x, r.y, L.sm_const[w.x], P, Q, tile, gmap, x0, y0, W);
+            }
         }
         __syncthreads();
     }
@@ -882,7 +923,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
             return;
         acc_t *cell = gmap + (size_t)px + (size_t)nn * (size_t)py;
         if (kIntCells<ACC>)  // exact tile sum -> one rounding to the accumulator type
-            atomicAdd(cell, (acc_t)((double)v * P.tile_inv_scale));
+            atomicAdd(cell, (acc_t)((double)v * Q.inv_scale));
         else
             atomicAdd(cell, (acc_t)v);
     };
@@ -1004,7 +1045,13 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
     const char *env_int = getenv("SLICER_K4_INT");
     const int int_mode = env_int ? atoi(env_int) : 1;
     const bool int_cells = int_mode == 2 || (int_mode == 1 && total_particles / (uint64_t)G.nbins >= 2048);
-    if (int_cells && !cfg.has_mass && (cfg.acc == kF32 || cfg.acc == kF64)) {
+    if (int_cells && (cfg.acc == kF32 || cfg.acc == kF64)) {
+        if (cfg.has_mass) {  // the quantum follows the largest mass the sort kernel saw (TileQuantum)
+            *int_cells_used = true;
+            if (cfg.acc == kF32)
+                return launch_k4<kTSC, kF32I>(pow2, true, P, G, L, T, I, F, max_items, s);
+            return launch_k4<kTSC, kF64I>(pow2, true, P, G, L, T, I, F, max_items, s);
+        }
         bool same_mass = true;  // one quantum per launch: all pending chunks carry the same constant mass
         for (int c = 1; c < L.n; c++)
             same_mass = same_mass && L.mconst[c] == L.mconst[0];

@@ -59,6 +59,7 @@ struct slicer_handle_s {
     PlaneBufs planes[SLICER_MAX_PLANES];
     unsigned long long *d_counts = nullptr;  // [SLICER_MAX_PLANES][6]
     int *d_neg = nullptr;
+    unsigned *d_maxmass = nullptr;  // [6] bits of the largest selected per-particle mass per species (this pass)
     bool type_seen[6] = {};       // in this plane pass
     bool shared_seen = false;
     int algo_mask = 0;            // bit (1 << SLICER_ALGO_*) of every algorithm that ran in this pass; bit 3 = thinning
@@ -430,6 +431,7 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
         T.nsel[p] = h->d_counts + (size_t)p * 6 + type;
     }
     T.neg_flag = h->d_neg;
+    T.max_mass = h->d_maxmass + type;
 }
 
 constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
@@ -1106,7 +1108,8 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
     h->max_chunk = max_chunk ? std::min<uint64_t>(max_chunk, 1ull << 30) : (1ull << 24);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->own) != hipSuccess ||
         hipMalloc((void **)&h->d_counts, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6) != hipSuccess ||
-        hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess) {
+        hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->d_maxmass, 6 * sizeof(unsigned)) != hipSuccess) {
         int rc = fail(nullptr, SLICER_ERR_HIP, "device %d initialisation failed: %s", device,
                       hipGetErrorString(hipGetLastError()));
         delete h;
@@ -1157,6 +1160,7 @@ int slicer_destroy(slicer_handle h)
     }
     if (h->d_counts) (void)hipFree(h->d_counts);
     if (h->d_neg) (void)hipFree(h->d_neg);
+    if (h->d_maxmass) (void)hipFree(h->d_maxmass);
     if (h->own) (void)hipStreamDestroy(h->own);
     delete h;
     return SLICER_OK;
@@ -1224,6 +1228,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     }
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_neg, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_maxmass, 0, 6 * sizeof(unsigned), h->stream));
     return SLICER_OK;
 }
 

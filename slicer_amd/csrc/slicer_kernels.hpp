@@ -18,6 +18,7 @@ struct Targets {
     void *acc[kMaxPlanes];                 // accumulator map of each plane (type-specific or shared)
     unsigned long long *nsel[kMaxPlanes];  // selected-entry counter of each plane for this type
     int *neg_flag;                         // set when any transformed coordinate is < 0
+    unsigned *max_mass;                    // bits of the largest selected per-particle mass of this species (sort kernel)
 };
 
 struct LaunchCfg {
