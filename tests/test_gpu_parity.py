@@ -1066,3 +1066,24 @@ def test_eight_planes_in_one_pass(S, ngp):
             assert np.array_equal(tot == 0, ref_tot == 0)
             d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
             assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
+
+
+@pytest.mark.parametrize("npix", [64, 1024])
+def test_hydro_integer_cells_with_masses_over_five_decades(S, npix):
+    """Per-particle masses set the quantum of the integer tile cells by their largest value (forced here by the module's
+    SLICER_K4_INT=2): contributions of the light particles then fall below 2^-25 of that scale far more often than with
+    one constant mass and take the side path (noted in LDS, or inline once the list is full -- the 64^2 map puts
+    everything into a few tiles).  The maps must stay inside the TSC bar against the oracle."""
+    n = 400000
+    rng = np.random.default_rng(17)
+    m0 = np.exp(rng.uniform(np.log(1e-4), np.log(10.0), n)).astype(np.float32)
+    m0[::101] = 5000.0  # above MAX_M: zeroed
+    f = dict(npart=[n, 0, 0, 0, 0, 0], massarr=[0.0] * 6, boxsize=BOX, pos=synth.positions(0, n, BOX, clustered=True),
+             mass={0: m0})
+    ref_tot, ref_toti, nsel = run_oracle([f], npix, 0.25, 3.0, 4.0, hydro=True)
+    (tot, toti, cnt), = run_gpu(S, [f], npix, 0.25, [3.0], [4.0], hydro=True, algo=slicer_amd.ALGO_BINNED)
+    assert S.algo_mask() & 64 and np.array_equal(cnt, nsel)
+    for got, ref in ((tot, ref_tot), (toti[0], ref_toti[0])):
+        assert np.array_equal(got == 0, ref == 0)
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref), float((d / np.maximum(ref, 1e-30)).max())
