@@ -218,6 +218,10 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
  * op 4 / 5: the 9-term variants of 2 / 3, |a| <= 0.155
  * op 6 / 7: the raw hardware estimates v_rsq_f64(a), v_rcp_f64(a)      op 8 / 9: their one-step refinements
  *           (rsqrt_fast / rcp_fast of the fast project+bin kernel: not correctly rounded, < 2^-48 relative)
+ * op 10: out = cell index floor((double)(float)a / dl) on a map of npix = (int)b & 0xFFFFF pixels (dl = 1 / npix, any
+ *           npix: utilities.cpp:69-70)      op 11: TSC weight number (int)b >> 20 (0, 1, 2) of that coordinate
+ *           (utilities.cpp:4-16, 82-88) -- the device evaluates both without the reference's f64 divisions except on
+ *           exact ties
  * Lets the tests compare these with correctly rounded host results bit by bit (densitymaps.cpp:382-384 uses
  * sqrt, /, asin, atan2 of libm). */
 int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *d_b, double *d_out, uint64_t n);

@@ -545,7 +545,7 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
 {
     memset(&A, 0, sizeof A);
     fast = false;
-    if (env_int("SLICER_K1_GENERAL") || P.n_planes > 4 || !(P.lim < 1.5) || G.region != G.batch || !P.pow2 ||
+    if (env_int("SLICER_K1_GENERAL") || P.n_planes > 4 || !(P.lim < 1.5) || G.region != G.batch ||
         (uint64_t)G.n_units * (uint64_t)nblocks * (uint64_t)G.region >= (1ull << 31))
         return SLICER_OK;
     for (int p = 0; p < P.n_planes; p++)
@@ -607,7 +607,9 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
     A.lim = P.lim;
     A.inv_fov = P.inv_fov;
     A.nn_f = P.nn_f;
+    A.nn_d = P.nn_d;
     A.nn = P.nn;
+    A.pow2 = P.pow2;
     fast = true;
     return SLICER_OK;
 }
@@ -1809,7 +1811,7 @@ int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *
 {
     if (!h)
         return fail(h, SLICER_ERR_ARG, "null handle");
-    if (op < 0 || op > 9 || (n && (!d_a || !d_out || (op == 1 && !d_b))) || n > (1ull << 31))
+    if (op < 0 || op > 11 || (n && (!d_a || !d_out || ((op == 1 || op >= 10) && !d_b))) || n > (1ull << 31))
         return fail(h, SLICER_ERR_ARG, "slicer_debug_math: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, launch_debug_math(op, d_a, d_b, d_out, n, h->stream));

@@ -359,12 +359,25 @@ __device__ __forceinline__ bool surely_outside_fov(float x, float y, float z, co
 // floor(x / dl) as int.   utilities.cpp:69-70
 // POW2 (dl = 2^-k): x / dl = x * 2^k, an exact scaling in f32 as well as in f64, so the f32 product and floorf()
 // give the reference's double-precision result without any fp64 instruction.
+// Any other nn (dl = RN64(1/nn) is not a power of two): the reference divides by dl in f64.  The product t = v * nn is
+// exact in f64 (24 + 17 bits), and the correctly rounded quotient RN64(v / dl) lies within one f64 ulp of it (dl is within
+// 2^-53 of 1/nn), so the two have the same floor unless t itself is an integer -- then the division decides.
+// grid_tie() tells the kernels that keep such entries out of their loops (k_project_bin_fast).
+__device__ __forceinline__ bool grid_tie(float v, const PassParams &P)
+{
+    const double t = (double)v * P.nn_d;
+    return t == floor(t);
+}
+
 template <bool POW2>
 __device__ __forceinline__ int grid_index(float v, const PassParams &P)
 {
     if (POW2)
         return (int)floorf(v * P.nn_f);
-    return (int)floor((double)v / P.dl);
+    const double t = (double)v * P.nn_d, f = floor(t);
+    if (t == f)  // rare (v = k / nn exactly)
+        return (int)floor((double)v / P.dl);
+    return (int)f;
 }
 
 // TSC weights of the three cells g-1, g, g+1 along one axis.   utilities.cpp:4-16, 82-88
@@ -402,7 +415,13 @@ __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, fl
         float D = v - c;
         float A = fabsf(D);
         double Ad = (double)A;
-        float u = (float)(Ad / P.dl);
+        // u = (float)(Ad / dl): the exact product q = A * nn (41 bits) and RN64(Ad / dl), one f64 ulp apart at most, round
+        // to the same f32 unless q sits exactly on the midpoint of two f32 values (its 29 low mantissa bits are 100..0):
+        // only then the division is carried out
+        const double q = Ad * P.nn_d;
+        float u = (float)q;
+        if (((unsigned)__double_as_longlong(q) & 0x1FFFFFFFu) == 0x10000000u)
+            u = (float)(Ad / P.dl);
         float W;
         if (Ad <= P.half_dl) {
             float uu = u * u;

@@ -520,7 +520,28 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
     case 6: r = __builtin_amdgcn_rsq(a[i]); break;  // the raw hardware estimates ...
     case 7: r = __builtin_amdgcn_rcp(a[i]); break;
     case 8: r = rsqrt_fast(a[i]); break;            // ... and their one-step refinements (k_project_bin_fast)
-    default: r = rcp_fast(a[i]); break;
+    case 9: r = rcp_fast(a[i]); break;
+    // 10 / 11: the grid arithmetic of a map that is not a power of two wide (npix in the low 20 bits of b): 10 = cell
+    // index of the f32 coordinate a; 11 = TSC weight number (int)b >> 20 (0..2) of that coordinate
+    default: {
+        PassParams P{};
+        const int nn = (int)b[i] & 0xFFFFF;
+        P.nn = nn;
+        P.pow2 = 0;
+        P.dl = 1. / double(nn);
+        P.nn_d = (double)nn;
+        P.half_dl = 0.5 * P.dl;
+        P.onehalf_dl = 0.5 * 3.0 * P.dl;
+        const float v = (float)a[i];
+        const int g = grid_index<false>(v, P);
+        if (op == 10) {
+            r = (double)g;
+        } else {
+            float w[3];
+            tsc_axis<false>(v, g, P, w);
+            r = (double)w[((int)b[i] >> 20) % 3];
+        }
+    } break;
     }
     out[i] = r;
 }

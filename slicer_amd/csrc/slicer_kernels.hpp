@@ -127,10 +127,13 @@ struct K1Args {
     int stack;                 // compact survivors through the wave stack before projecting (few survivors) or not
     // conservative FOV pre-test
     float k_ra, eps_ra, k_dec, eps_dec;
-    // projection + grid (power-of-two maps)
+    // projection + grid
     double series_max, lim, inv_fov;
+    double nn_d;               // (double)nn
     float nn_f;
     int nn;
+    int pow2;                  // nn is a power of two: the cell index is floorf(xs * nn_f); else floor(xs * nn_d) with
+                               // exact cell boundaries left to the exact epilogue (grid_tie, slicer_device.hpp)
     // tile geometry (BinGeom)
     int tw_log2, th_log2, ntx, tiles_per_unit, units_per_plane, rows_per_unit, n_units, nbins, batch;
 };

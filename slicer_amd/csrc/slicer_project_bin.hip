@@ -8,8 +8,8 @@
 // on a full wave.  There is no workgroup barrier in the loop; waves only share the histogram and the output cursors.
 //
 // Two variants of the kernel:
-//   k_project_bin_fast     the common case (<= 4 planes per pass, no lateral replication, box size and random centre
-//                          that passed the host's exactness checks).  The kernel is bound by VALU issue, so this
+//   k_project_bin_fast     the common case (<= 4 planes per pass, no lateral replication, any map size, box size and
+//                          random centre that passed the host's exactness checks).  The kernel is bound by VALU issue, so this
 //                          variant is written for instruction count:
 //                            * r/box as a correctly rounded f32 division (reciprocal + two FMAs) instead of an fp64
 //                              product with a rounding-tie test -- valid for a box size iff an exhaustive device sweep
@@ -147,13 +147,12 @@ constexpr unsigned kExcCap = 256;
 
 // binning + emission of one selected entry (xs, ys) of `plane`: cursor in (unit, workgroup)'s region, record, histogram
 // (s_hist / s_out / s_cnt: the workgroup's histogram, record cursors [kMaxUnits] and NGP selected-entry counters)
+// (gx, gy) = cell of (xs, ys), utilities.cpp:69-70
 __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt, bool valid,
-                                            int plane, float xs, float ys, unsigned idx_in_batch, uint64_t b0,
-                                            float2 *out_wg, unsigned unit_stride)
+                                            int plane, float xs, float ys, int gx, int gy, unsigned idx_in_batch,
+                                            uint64_t b0, float2 *out_wg, unsigned unit_stride)
 {
     const bool ngp = A.ngp != 0;
-    int gx = (int)floorf(xs * A.nn_f);  // utilities.cpp:69-70 on a power-of-two map: exact scaling
-    int gy = (int)floorf(ys * A.nn_f);
     const int nn = A.nn;
     bool emit = valid;
     if (ngp) {
@@ -201,14 +200,17 @@ __device__ SLICER_SLOWPATH bool process_exact(const K1Kernarg *Kk, unsigned *s_h
         if (!(z >= P.zlo[p] && z < P.zhi[p]))
             continue;
         float xs, ys;
-        if (project<0>(x, y, z, 0, 0, P, xs, ys))
-            emit_record(A, s_hist, s_out, s_cnt, true, p, xs, ys, idx_in_batch, b0, out_wg, unit_stride);
+        if (project<0>(x, y, z, 0, 0, P, xs, ys)) {
+            const int gx = P.pow2 ? grid_index<true>(xs, P) : grid_index<false>(xs, P);
+            const int gy = P.pow2 ? grid_index<true>(ys, P) : grid_index<false>(ys, P);
+            emit_record(A, s_hist, s_out, s_cnt, true, p, xs, ys, gx, gy, idx_in_batch, b0, out_wg, unit_stride);
+        }
     }
     return neg;
 }
 
 // Fast projection (A3) of one selected entry per lane + emission; entries it cannot decide are noted for the epilogue.
-template <int SERIES>
+template <int SERIES, bool POW2>
 __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
                                              unsigned *s_exc, unsigned *s_nexc, bool have, float ex, float ey, float ez,
                                              unsigned tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
@@ -226,19 +228,32 @@ __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, 
     // tie of a map coordinate
     const double sx = fma(dec, A.inv_fov, 0.5), sy = fma(ra, A.inv_fov, 0.5);
     const bool dx = round_decided(sx, kMapWindow, xs), dy = round_decided(sy, kMapWindow, ys);
-    const bool undecided = !(fabs(sn) <= A.series_max && fabs(tn) <= A.series_max && ez > 0.0f) ||
-                           fabs(adec - A.lim) <= kAngWindow || fabs(ara - A.lim) <= kAngWindow || !dx || !dy;
+    bool undecided = !(fabs(sn) <= A.series_max && fabs(tn) <= A.series_max && ez > 0.0f) ||
+                     fabs(adec - A.lim) <= kAngWindow || fabs(ara - A.lim) <= kAngWindow || !dx || !dy;
+    // cell of the entry: on a power-of-two map the f32 product is exact; otherwise the exact f64 product, with an entry
+    // exactly on a cell boundary left to the epilogue (the reference's division decides there: grid_index<false>)
+    int gx, gy;
+    if (POW2) {
+        gx = (int)floorf(xs * A.nn_f);
+        gy = (int)floorf(ys * A.nn_f);
+    } else {
+        const double tx = (double)xs * A.nn_d, ty = (double)ys * A.nn_d;
+        const double fx = floor(tx), fy = floor(ty);
+        undecided = undecided || tx == fx || ty == fy;
+        gx = (int)fx;
+        gy = (int)fy;
+    }
     if (have && undecided)  // rare: noted for the exact epilogue
         s_exc[min(atomicAdd(s_nexc, 1u), kExcCap - 1)] = tag >> 3;
     const bool valid = have && !undecided && adec <= A.lim && ara <= A.lim;
-    emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, tag >> 3, b0, out_wg, unit_stride);
+    emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, gx, gy, tag >> 3, b0, out_wg, unit_stride);
 }
 
 // STACK: survivors of the slab / pre-test are compacted through the wave stack so that the projection runs on full
 // waves (pays when few particles survive: one plane per pass keeps ~20 %); !STACK: the projection runs in place on the
 // lanes that survive (pays when most do: the four planes of a replication keep ~78 %, and the LDS traffic and the
 // write -> read round trips of the stack cost more than the idle lanes).
-template <int FACE, int SERIES, bool STACK>
+template <int FACE, int SERIES, bool STACK, bool POW2>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin_fast(K1Kernarg K)
 {
     const K1Args &A = K.A;  // K.P is read through the kernarg segment by the exact epilogue only
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 }
                 top += (unsigned)__popcll(mask);
             } else if (mask != 0ull) {
-                project_emit<SERIES>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, sel, x, y, z, tag, b0, out_wg, unit_stride);
+                project_emit<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, sel, x, y, z, tag, b0, out_wg, unit_stride);
             }
         }
         if (STACK) {
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 if (have)
                     ent = q4[top - take + lane];
                 top -= take;
-                project_emit<SERIES>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, have, ent.x, ent.y, ent.z,
+                project_emit<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, have, ent.x, ent.y, ent.z,
                                      __float_as_uint(ent.w), b0, out_wg, unit_stride);
             }
             lds_fence();
@@ -656,18 +671,26 @@ static hipError_t launch_k1_fast(bool s9, int nb, size_t lds, const PassParams &
     K1Kernarg K;
     K.P = P;
     K.A = A;
-#define K1F(S_, ST_)                                                                  \
+#define K1F_(S_, ST_, P2_)                                                            \
     do {                                                                              \
-        auto kern = k_project_bin_fast<FACE, S_, ST_>;                                \
+        auto kern = k_project_bin_fast<FACE, S_, ST_, P2_>;                           \
         if ((e = set_lds(kern, lds)) != hipSuccess)                                   \
             return e;                                                                 \
         kern<<<nb, kK1Block, lds, s>>>(K);                                            \
+    } while (0)
+#define K1F(S_, ST_)                                                                  \
+    do {                                                                              \
+        if (A.pow2)                                                                   \
+            K1F_(S_, ST_, true);                                                      \
+        else                                                                          \
+            K1F_(S_, ST_, false);                                                     \
     } while (0)
     if (A.stack) {
         if (s9) K1F(9, true); else K1F(15, true);
     } else {
         if (s9) K1F(9, false); else K1F(15, false);
     }
+#undef K1F_
 #undef K1F
     return hipGetLastError();
 }

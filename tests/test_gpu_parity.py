@@ -1087,3 +1087,69 @@ def test_hydro_integer_cells_with_masses_over_five_decades(S, npix):
         assert np.array_equal(got == 0, ref == 0)
         d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
         assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref), float((d / np.maximum(ref, 1e-30)).max())
+
+
+@pytest.mark.parametrize("npix", [100, 300, 1000, 4000, 7745, 65535])
+def test_grid_arithmetic_of_maps_that_are_not_a_power_of_two(S, npix):
+    """utilities.cpp:69-70 and :4-16 divide by dl = 1/npix in f64.  The device multiplies by npix (an exact product) and
+    divides only on exact ties -- a coordinate that is k / npix exactly, or a quotient on the midpoint of two f32 values.
+    Cell index and the three weights against the reference's own expressions in numpy doubles, bit for bit, on random
+    coordinates, on every representable k / npix, and on constructed midpoint cases."""
+    rng = np.random.default_rng(npix)
+    dl = 1.0 / float(npix)
+    v = rng.uniform(-1.5 * dl, 1.0 + 1.5 * dl, 400000).astype(np.float32)
+    ks = np.arange(0, npix + 1, dtype=np.float64)
+    exact = (ks / npix).astype(np.float32)
+    exact = exact[exact.astype(np.float64) * npix == np.round(exact.astype(np.float64) * npix)]  # k / npix exactly in f32
+    # |v - c| * npix on an f32 midpoint: c of a random cell, then offsets A = (m + 0.5) ulp-steps / npix where that is f32
+    cells = rng.integers(0, npix, 200000)
+    c = ((cells + 0.5) * dl).astype(np.float32)
+    m = (rng.integers(1 << 22, 1 << 23, cells.size) * 2 + 1).astype(np.float64) * 2.0 ** -25   # odd multiples: midpoints
+    A = (m / npix).astype(np.float32)
+    mid = np.concatenate([c + A, c - A]).astype(np.float32)
+    v = np.concatenate([v, exact, np.nextafter(exact, np.float32(2)), np.nextafter(exact, np.float32(-1)), mid])
+    vd = v.astype(np.float64)
+    g_ref = np.floor(vd / dl)
+    g = S.debug_math(10, vd, np.full(v.size, float(npix)))
+    assert np.array_equal(g, g_ref), int((g != g_ref).sum())
+    n_tie = int((vd * npix == np.floor(vd * npix)).sum())
+    n_mid = 0
+    for a in range(3):
+        p = g_ref + a - 1
+        cc = ((p + 0.5) * dl).astype(np.float32)
+        Aa = np.abs(v - cc)
+        Ad = Aa.astype(np.float64)
+        u = (Ad / dl).astype(np.float32)
+        q = Ad * npix
+        n_mid += int(((q.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)).sum())
+        w = np.where(Ad <= 0.5 * dl, (0.75 - (u * u).astype(np.float64)).astype(np.float32),
+                     np.where(Ad <= 0.5 * 3.0 * dl, (0.5 * ((1.5 - u.astype(np.float64)) ** 2)).astype(np.float32), np.float32(0)))
+        got = S.debug_math(11, vd, np.full(v.size, float(npix + (a << 20)))).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)), (a, int((got != w).sum()))
+    assert n_tie > 0   # the tie paths were exercised ...
+    print(f"npix {npix}: {v.size} coordinates, {n_tie} exact cell boundaries, {n_mid} midpoint quotients")
+
+
+@pytest.mark.parametrize("npix", [300, 1000, 4000])
+def test_fast_project_bin_kernel_on_maps_that_are_not_a_power_of_two(S, npix):
+    """The fast project+bin kernel takes any map size: the cell of an entry is floor(xs * npix) from the exact f64
+    product, entries exactly on a cell boundary go to its exact epilogue.  NGP bit for bit against the oracle (four planes,
+    f32 centre, coordinates on the box faces included), and fixed-point TSC identical to the fused kernel's."""
+    f32c = tuple(float(np.float32(c)) for c in RND["center"])
+    rnd = dict(RND, center=f32c)
+    vals = np.array([0.0, BOX, 0.5 * BOX, 0.25 * BOX, 0.999999 * BOX], np.float32)
+    edge = np.array(list(itertools.product(vals, repeat=3)), np.float32)
+    pos = np.concatenate([synth.positions(0, 300000, BOX), edge])
+    f = dict(npart=[0, len(pos), 0, 0, 0, 0], massarr=[0, 0.0123, 0, 0, 0, 0], boxsize=BOX, pos=pos)
+    lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
+    out = run_gpu(S, [f], npix, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    assert S.algo_mask() & 16 and not S.algo_mask() & 32
+    for p in range(4):
+        ref_tot, ref_toti, nsel = run_oracle([f], npix, 0.25, lds[p], ld2s[p], ngp=True, rnd=rnd)
+        assert np.array_equal(out[p][2], nsel) and nsel.sum() > 0
+        assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32))
+    a = run_gpu(S, [f], npix, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    assert S.algo_mask() & 16
+    b = run_gpu(S, [f], npix, 0.25, lds, ld2s, accum=slicer_amd.ACC_FIXED64, algo=slicer_amd.ALGO_DIRECT, rnd=rnd)
+    for p in range(4):
+        assert np.array_equal(a[p][0].view(np.uint32), b[p][0].view(np.uint32))
