@@ -322,6 +322,12 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
     P.nn_f = (float)P.nn_d;
     P.half_dl_f = (float)P.half_dl;
     P.onehalf_dl_f = (float)P.onehalf_dl;
+    auto round_down = [](double x) {
+        float f = (float)x;
+        return (double)f > x ? std::nextafterf(f, 0.0f) : f;
+    };
+    P.half_dl_lo = round_down(P.half_dl);
+    P.onehalf_dl_lo = round_down(P.onehalf_dl);
     P.mconst = (float)f.massarr[type];  // densitymaps.cpp:372
     P.sm_const = sqrtf(P.mconst);       // glibc sqrtf is correctly rounded, as std::sqrt(float)
     int e = d.want_type_maps ? h->fixed_exp[type] : h->fixed_exp_shared;

@@ -51,6 +51,7 @@ struct PassParams {
     double half_dl;  // 0.5 * dl
     double onehalf_dl;  // 0.5 * 3.0 * dl
     float dl_f, nn_f, half_dl_f, onehalf_dl_f;  // the same as f32: exact when nn is a power of two (pow2 paths only)
+    float half_dl_lo, onehalf_dl_lo;  // largest f32 <= half_dl / onehalf_dl: (double)A <= half_dl  <=>  A <= half_dl_lo
     // --- mass (densitymaps.cpp:358-372) ---
     float mconst;    // (float)massarr[t]
     float sm_const;  // sqrtf(mconst), IEEE correctly rounded
@@ -408,31 +409,27 @@ __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, fl
         w[2] = 0.5f * (t2 * t2);
         return;
     }
+    // Any other nn: the reference's sequence with every step that is provably exact moved to f32 --
+    //   (double)p + 0.5 = (double)g + (a - 0.5), exact;  c = (float)(that * dl) as written
+    //   (double)A <= half_dl  <=>  A <= RD32(half_dl): A is an f32 value (thresholds prepared by the host)
+    //   u = (float)((double)A / dl): exact product with nn unless on an f32 midpoint (see below)
+    //   (float)(0.75 - (double)(u*u)), 1.5 - (double)u, (float)(0.5 * (t*t)): as in the power-of-two case above -- those
+    //   arguments use only that u*u and (for u >= 0.5) 1.5 - u are f32 values, not the map size
+    const double gd = (double)g;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        int p = g + a - 1;
-        float c = (float)(((double)p + 0.5) * P.dl);
-        float D = v - c;
-        float A = fabsf(D);
-        double Ad = (double)A;
+        const float c = (float)((gd + ((double)a - 0.5)) * P.dl);
+        const float A = fabsf(v - c);
         // u = (float)(Ad / dl): the exact product q = A * nn (41 bits) and RN64(Ad / dl), one f64 ulp apart at most, round
         // to the same f32 unless q sits exactly on the midpoint of two f32 values (its 29 low mantissa bits are 100..0):
         // only then the division is carried out
-        const double q = Ad * P.nn_d;
+        const double q = (double)A * P.nn_d;
         float u = (float)q;
         if (((unsigned)__double_as_longlong(q) & 0x1FFFFFFFu) == 0x10000000u)
-            u = (float)(Ad / P.dl);
-        float W;
-        if (Ad <= P.half_dl) {
-            float uu = u * u;
-            W = (float)(0.75 - (double)uu);
-        } else if (Ad <= P.onehalf_dl) {
-            double t = 1.5 - (double)u;
-            W = (float)(0.5 * (t * t));
-        } else {
-            W = 0.0f;
-        }
-        w[a] = W;
+            u = (float)((double)A / P.dl);
+        const float t = 1.5f - u;
+        const float w_in = 0.75f - u * u, w_out = 0.5f * (t * t);
+        w[a] = A <= P.half_dl_lo ? w_in : (A <= P.onehalf_dl_lo ? w_out : 0.0f);
     }
 }
 

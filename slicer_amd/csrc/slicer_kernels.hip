@@ -532,6 +532,10 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
         P.nn_d = (double)nn;
         P.half_dl = 0.5 * P.dl;
         P.onehalf_dl = 0.5 * 3.0 * P.dl;
+        float lo = (float)P.half_dl;
+        P.half_dl_lo = (double)lo > P.half_dl ? __uint_as_float(__float_as_uint(lo) - 1u) : lo;
+        lo = (float)P.onehalf_dl;
+        P.onehalf_dl_lo = (double)lo > P.onehalf_dl ? __uint_as_float(__float_as_uint(lo) - 1u) : lo;
         const float v = (float)a[i];
         const int g = grid_index<false>(v, P);
         if (op == 10) {
