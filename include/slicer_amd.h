@@ -219,7 +219,8 @@ int slicer_debug_project(slicer_handle h, int type, const float *d_pos, uint64_t
  * op 6 / 7: the raw hardware estimates v_rsq_f64(a), v_rcp_f64(a)      op 8 / 9: their one-step refinements
  *           (rsqrt_fast / rcp_fast of the fast project+bin kernel: not correctly rounded, < 2^-48 relative)
  * op 10: out = cell index floor((double)(float)a / dl) on a map of npix = (int)b & 0xFFFFF pixels (dl = 1 / npix, any
- *           npix: utilities.cpp:69-70)      op 11: TSC weight number (int)b >> 20 (0, 1, 2) of that coordinate
+ *           npix: utilities.cpp:69-70)      op 11: TSC weight number ((int)b >> 20) & 3 (0, 1, 2) of that coordinate;
+ *           bit 22 of b selects the reciprocal-product quotient a clean slicer_debug_dl_quotient sweep licenses
  *           (utilities.cpp:4-16, 82-88) -- the device evaluates both without the reference's f64 divisions except on
  *           exact ties
  * Lets the tests compare these with correctly rounded host results bit by bit (densitymaps.cpp:382-384 uses
@@ -231,6 +232,11 @@ int slicer_debug_math(slicer_handle h, int op, const double *d_a, const double *
  * device compares it with (float)((double)r / box); *n_bad = number of mismatches (0 = licensed), examples8 = bit
  * patterns of up to eight offending r.  The library runs the same sweep once per handle and box size. */
 int slicer_debug_box_quotient(slicer_handle h, double box, uint32_t *n_bad, uint32_t *examples8);
+/* The same kind of proof for maps that are not a power of two wide: the grid arithmetic divides by dl = 1/npix in
+ * f64 (utilities.cpp:69-70, :4-16); the device replaces the division by a reciprocal product + one FMA correction
+ * (quot_dl3, slicer_device.hpp) for a map size only after this sweep -- every non-negative f32 operand below 2 against
+ * the IEEE division, ~1 ms, run once per npix and handle -- found no mismatch.  n_bad = mismatches (0 expected). */
+int slicer_debug_dl_quotient(slicer_handle h, int32_t npix, uint32_t *n_bad, uint32_t *examples8);
 
 /* per-kernel HIP-event timing (off by default; adds two event records per launch) */
 int slicer_profile_enable(slicer_handle h, int on);

@@ -68,6 +68,7 @@ SYMBOLS = {
     "slicer_debug_project": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "slicer_debug_box_quotient": (C.c_int, [_H, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "slicer_debug_dl_quotient": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "slicer_debug_math": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "slicer_profile_enable": (C.c_int, [_H, C.c_int]),
     "slicer_profile_reset": (C.c_int, [_H]),

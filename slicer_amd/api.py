@@ -276,6 +276,13 @@ class Slicer:
         self._chk(_L.slicer_debug_box_quotient(self._h, float(box), C.byref(n), ex))
         return n.value, np.array(list(ex), np.uint32).view(np.float32)[:min(n.value, 8)]
 
+    def debug_dl_quotient(self, npix):
+        """Exhaustive device check of the division-free grid quotient for a map size; -> (mismatches, example f32s)."""
+        n = C.c_uint32(0)
+        ex = (C.c_uint32 * 8)()
+        self._chk(_L.slicer_debug_dl_quotient(self._h, int(npix), C.byref(n), ex))
+        return n.value, np.array(list(ex), np.uint32).view(np.float32)[:min(n.value, 8)]
+
     def debug_math(self, op, a, b=None):
         """Device sqrt (op 0), quotient (1), small-angle asin (2) / atan (3) of float64 arrays; see slicer_amd.h."""
         a = np.ascontiguousarray(a, np.float64)

@@ -86,6 +86,8 @@ struct slicer_handle_s {
     // box sizes whose f32 quotient r/box passed (true) or failed (false) the exhaustive device sweep
     // (launch_check_box_quotient): k_project_bin_fast is only used for the former
     std::vector<std::pair<double, bool>> box_verdicts;
+    std::vector<std::pair<int, bool>> dl_verdicts;  // map sizes (not powers of two) whose quot_dl3 passed / failed its sweep
+    bool dl_quot_ok = false;                        // ... the verdict for the current pass's npix
     unsigned *d_sweep = nullptr;
     DevBuf w_tcounts, w_tbase, w_urand;  // shot-noise thinning (snopt > 0)
     std::vector<float> h_urand;
@@ -326,6 +328,8 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
         float f = (float)x;
         return (double)f > x ? std::nextafterf(f, 0.0f) : f;
     };
+    P.inv_dl = 1.0 / P.dl;
+    P.dl_quot_ok = (!P.pow2 && h->dl_quot_ok) ? 1 : 0;
     P.half_dl_lo = round_down(P.half_dl);
     P.onehalf_dl_lo = round_down(P.onehalf_dl);
     P.mconst = (float)f.massarr[type];  // densitymaps.cpp:372
@@ -542,6 +546,31 @@ int box_quotient_ok(slicer_handle h, double box, bool &ok)
         return rc;
     ok = out[0] == 0;
     h->box_verdicts.emplace_back(box, ok);
+    return SLICER_OK;
+}
+
+// Maps that are not a power of two wide: may the grid arithmetic use quot_dl3 instead of f64 divisions by dl = 1/npix?
+// One exhaustive device sweep (2^30 operands, ~1 ms) per distinct npix and handle, cached.  SLICER_DL_QUOT=0 says no.
+int dl_quotient_ok(slicer_handle h, int npix, bool &ok, unsigned *examples9 = nullptr)
+{
+    if (!examples9)
+        for (auto &v : h->dl_verdicts)
+            if (v.first == npix) {
+                ok = v.second;
+                return SLICER_OK;
+            }
+    if (!h->d_sweep)
+        HIPCHK(h, hipMalloc((void **)&h->d_sweep, 9 * sizeof(unsigned)));
+    HIPCHK(h, hipMemsetAsync(h->d_sweep, 0, 9 * sizeof(unsigned), h->stream));
+    HIPCHK(h, launch_check_dl_quotient(1. / double(npix), h->d_sweep, h->stream));
+    unsigned out[9] = {1};
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sweep, sizeof out, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ok = out[0] == 0;
+    if (examples9)
+        memcpy(examples9, out, sizeof out);
+    else
+        h->dl_verdicts.emplace_back(npix, ok);
     return SLICER_OK;
 }
 
@@ -1205,6 +1234,12 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
             return fail(h, SLICER_ERR_ARG, "nrepperp[%d] = %d out of range 0..8", p, desc->nrepperp[p]);
     HIPCHK(h, hipSetDevice(h->device));
     h->desc = *desc;
+    h->dl_quot_ok = false;
+    if (!is_pow2(desc->npix) && env_int("SLICER_DL_QUOT", 1)) {
+        int rcq = dl_quotient_ok(h, desc->npix, h->dl_quot_ok);
+        if (rcq)
+            return rcq;
+    }
     h->npix2 = (uint64_t)desc->npix * (uint64_t)desc->npix;
     h->in_plane = true;
     h->in_file = false;
@@ -1805,6 +1840,22 @@ int slicer_debug_box_quotient(slicer_handle h, double box, uint32_t *n_bad, uint
     HIPCHK(h, hipSetDevice(h->device));
     unsigned out[9];
     int rc = run_box_sweep(h, box, out);
+    if (rc)
+        return rc;
+    *n_bad = out[0];
+    if (examples8)
+        memcpy(examples8, out + 1, 8 * sizeof(uint32_t));
+    return SLICER_OK;
+}
+
+int slicer_debug_dl_quotient(slicer_handle h, int32_t npix, uint32_t *n_bad, uint32_t *examples8)
+{
+    if (!h || !n_bad || npix < 1 || npix > 65536)
+        return fail(h, SLICER_ERR_ARG, "slicer_debug_dl_quotient: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned out[9];
+    bool ok;
+    int rc = dl_quotient_ok(h, npix, ok, out);
     if (rc)
         return rc;
     *n_bad = out[0];

@@ -52,6 +52,9 @@ struct PassParams {
     double onehalf_dl;  // 0.5 * 3.0 * dl
     float dl_f, nn_f, half_dl_f, onehalf_dl_f;  // the same as f32: exact when nn is a power of two (pow2 paths only)
     float half_dl_lo, onehalf_dl_lo;  // largest f32 <= half_dl / onehalf_dl: (double)A <= half_dl  <=>  A <= half_dl_lo
+    double inv_dl;   // RN64(1 / dl)
+    int dl_quot_ok;  // quot_dl()'s three-operation quotient was proven against the IEEE division for this dl (device
+                     // sweep over every f32 operand below 2, k_check_dl_quotient); 0: divide
     // --- mass (densitymaps.cpp:358-372) ---
     float mconst;    // (float)massarr[t]
     float sm_const;  // sqrtf(mconst), IEEE correctly rounded
@@ -360,6 +363,17 @@ __device__ __forceinline__ bool surely_outside_fov(float x, float y, float z, co
 // floor(x / dl) as int.   utilities.cpp:69-70
 // POW2 (dl = 2^-k): x / dl = x * 2^k, an exact scaling in f32 as well as in f64, so the f32 product and floorf()
 // give the reference's double-precision result without any fp64 instruction.
+// RN64(n / dl) for the f32 operands of the grid arithmetic (0 <= n < 2).  With y = RN64(1/dl): q0 = RN(n y), the exact
+// residual r = n - dl q0 by FMA, q = RN(q0 + r y) -- Markstein's correction step, which returns the correctly rounded
+// quotient for all but special divisors; whether dl is one is not argued but measured: the host enables this path
+// for a map size only after k_check_dl_quotient compared it with the IEEE division on every f32 operand below 2.
+__device__ __forceinline__ double quot_dl3(double n, double dl, double inv_dl)
+{
+    const double q0 = n * inv_dl;
+    const double r = fma(-dl, q0, n);
+    return fma(r, inv_dl, q0);
+}
+
 // Any other nn (dl = RN64(1/nn) is not a power of two): the reference divides by dl in f64.  The product t = v * nn is
 // exact in f64 (24 + 17 bits), and the correctly rounded quotient RN64(v / dl) lies within one f64 ulp of it (dl is within
 // 2^-53 of 1/nn), so the two have the same floor unless t itself is an integer -- then the division decides.
@@ -375,6 +389,8 @@ __device__ __forceinline__ int grid_index(float v, const PassParams &P)
 {
     if (POW2)
         return (int)floorf(v * P.nn_f);
+    if (P.dl_quot_ok)  // (holds for |v| < 2: anything further out is far off the map either way -- but keep it exact)
+        return (int)floor(fabsf(v) < 2.0f ? quot_dl3((double)v, P.dl, P.inv_dl) : (double)v / P.dl);
     const double t = (double)v * P.nn_d, f = floor(t);
     if (t == f)  // rare (v = k / nn exactly)
         return (int)floor((double)v / P.dl);
@@ -423,10 +439,15 @@ __device__ __forceinline__ void tsc_axis(float v, int g, const PassParams &P, fl
         // u = (float)(Ad / dl): the exact product q = A * nn (41 bits) and RN64(Ad / dl), one f64 ulp apart at most, round
         // to the same f32 unless q sits exactly on the midpoint of two f32 values (its 29 low mantissa bits are 100..0):
         // only then the division is carried out
-        const double q = (double)A * P.nn_d;
-        float u = (float)q;
-        if (((unsigned)__double_as_longlong(q) & 0x1FFFFFFFu) == 0x10000000u)
-            u = (float)((double)A / P.dl);
+        float u;
+        if (P.dl_quot_ok && A < 2.0f) {  // wave-uniform in practice: three operations instead of the division
+            u = (float)quot_dl3((double)A, P.dl, P.inv_dl);
+        } else {
+            const double q = (double)A * P.nn_d;
+            u = (float)q;
+            if (((unsigned)__double_as_longlong(q) & 0x1FFFFFFFu) == 0x10000000u)
+                u = (float)((double)A / P.dl);
+        }
         const float t = 1.5f - u;
         const float w_in = 0.75f - u * u, w_out = 0.5f * (t * t);
         w[a] = A <= P.half_dl_lo ? w_in : (A <= P.onehalf_dl_lo ? w_out : 0.0f);

@@ -503,6 +503,23 @@ hipError_t launch_debug_project(const float *d_pos, uint64_t n, const PassParams
     return hipGetLastError();
 }
 
+// Exhaustive check of quot_dl3 against the IEEE division for one dl: every non-negative f32 below 2 (2^30 operands; the
+// negative ones follow by symmetry of every operation involved).  out[0] = mismatches, out[1..8] = examples (f32 bits).
+__global__ __launch_bounds__(256) void k_check_dl_quotient(double dl, double inv_dl, unsigned *out)
+{
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < 0x40000000ull; u += stride) {
+        const double n = (double)__uint_as_float((unsigned)u);
+        const double ref = n / dl;
+        const double got = quot_dl3(n, dl, inv_dl);
+        if (__double_as_longlong(ref) != __double_as_longlong(got)) {
+            const unsigned k = atomicAdd(out, 1u);
+            if (k < 8)
+                out[1 + k] = (unsigned)u;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__restrict__ a, const double *__restrict__ b,
                                                     double *__restrict__ out, uint64_t n)
 {
@@ -536,6 +553,8 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
         P.half_dl_lo = (double)lo > P.half_dl ? __uint_as_float(__float_as_uint(lo) - 1u) : lo;
         lo = (float)P.onehalf_dl;
         P.onehalf_dl_lo = (double)lo > P.onehalf_dl ? __uint_as_float(__float_as_uint(lo) - 1u) : lo;
+        P.inv_dl = 1.0 / P.dl;
+        P.dl_quot_ok = ((int)b[i] >> 22) & 1;  // bit 22 of b: the three-operation quotient (as after a clean sweep)
         const float v = (float)a[i];
         const int g = grid_index<false>(v, P);
         if (op == 10) {
@@ -543,11 +562,17 @@ __global__ __launch_bounds__(256) void k_debug_math(int op, const double *__rest
         } else {
             float w[3];
             tsc_axis<false>(v, g, P, w);
-            r = (double)w[((int)b[i] >> 20) % 3];
+            r = (double)w[(((int)b[i] >> 20) & 3) % 3];
         }
     } break;
     }
     out[i] = r;
+}
+
+hipError_t launch_check_dl_quotient(double dl, unsigned *d_out9, hipStream_t s)
+{
+    k_check_dl_quotient<<<256 * 16, 256, 0, s>>>(dl, 1.0 / dl, d_out9);
+    return hipGetLastError();
 }
 
 hipError_t launch_debug_math(int op, const double *d_a, const double *d_b, double *d_out, uint64_t n, hipStream_t s)

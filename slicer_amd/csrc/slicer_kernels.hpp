@@ -139,6 +139,8 @@ struct K1Args {
 };
 
 // exhaustive device check of the f32 form of r / box used by k_project_bin_fast (all 2^31 non-negative floats)
+// exhaustive device check of quot_dl3 (slicer_device.hpp) for one map size; d_out9 zeroed by the caller
+hipError_t launch_check_dl_quotient(double dl, unsigned *d_out9, hipStream_t s);
 hipError_t launch_check_box_quotient(double box, unsigned *d_mismatches, hipStream_t s);
 
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);

@@ -1110,8 +1110,11 @@ def test_grid_arithmetic_of_maps_that_are_not_a_power_of_two(S, npix):
     v = np.concatenate([v, exact, np.nextafter(exact, np.float32(2)), np.nextafter(exact, np.float32(-1)), mid])
     vd = v.astype(np.float64)
     g_ref = np.floor(vd / dl)
-    g = S.debug_math(10, vd, np.full(v.size, float(npix)))
-    assert np.array_equal(g, g_ref), int((g != g_ref).sum())
+    n_bad, _ = S.debug_dl_quotient(npix)
+    assert n_bad == 0            # the sweep that licenses the division-free quotient for this map size
+    for quot in (0, 1 << 22):    # the exact-product form with divisions on ties, and the reciprocal-product quotient
+        g = S.debug_math(10, vd, np.full(v.size, float(npix + quot)))
+        assert np.array_equal(g, g_ref), (quot, int((g != g_ref).sum()))
     n_tie = int((vd * npix == np.floor(vd * npix)).sum())
     n_mid = 0
     for a in range(3):
@@ -1124,8 +1127,9 @@ def test_grid_arithmetic_of_maps_that_are_not_a_power_of_two(S, npix):
         n_mid += int(((q.view(np.uint64) & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)).sum())
         w = np.where(Ad <= 0.5 * dl, (0.75 - (u * u).astype(np.float64)).astype(np.float32),
                      np.where(Ad <= 0.5 * 3.0 * dl, (0.5 * ((1.5 - u.astype(np.float64)) ** 2)).astype(np.float32), np.float32(0)))
-        got = S.debug_math(11, vd, np.full(v.size, float(npix + (a << 20)))).astype(np.float32)
-        assert np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)), (a, int((got != w).sum()))
+        for quot in (0, 1 << 22):
+            got = S.debug_math(11, vd, np.full(v.size, float(npix + (a << 20) + quot))).astype(np.float32)
+            assert np.array_equal(got.view(np.uint32), w.astype(np.float32).view(np.uint32)), (a, quot, int((got != w).sum()))
     assert n_tie > 0   # the tie paths were exercised ...
     print(f"npix {npix}: {v.size} coordinates, {n_tie} exact cell boundaries, {n_mid} midpoint quotients")
 
