@@ -65,7 +65,7 @@ bad = 0
 for seed in range(400, 400 + (int(sys.argv[3]) if len(sys.argv) > 3 else 120)):
     rng = np.random.default_rng(seed)
     S = slicer_amd.Slicer(0, max_chunk=int(rng.choice([70000, 100000, 1 << 20])))
-    npix = int(rng.choice([64, 128, 256, 1024]))
+    npix = int(rng.choice([64, 100, 128, 256, 317, 1000, 1024]))
     n_planes = int(rng.integers(1, 5))
     edges = np.repeat(np.linspace(0.0, 1.0, n_planes + 1), 2)[1:-1]
     lds = [3.0 + float(e) for e in edges[0::2]]
