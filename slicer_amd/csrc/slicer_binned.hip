@@ -49,20 +49,42 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const unsigned short *__re
     const size_t stride16 = (size_t)((nbins + 1) >> 1) * 2;
     const int per = (nblocks + kScanSegs - 1) / kScanSegs;
     const int lo = seg * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    // (up to kKeep rows per lane -- 512 K1 workgroups give 16 -- stay in registers between the two passes: one read)
+    constexpr int kKeep = 16;
+    unsigned short keep[kKeep];
+    const bool kept = per <= kKeep;
     unsigned sum = 0;
-    if (bin < nbins)
-        for (int b = lo; b < hi; b++)
-            sum += hist16[(size_t)b * stride16 + bin];
+    if (bin < nbins) {
+        if (kept) {
+#pragma unroll
+            for (int j = 0; j < kKeep; j++) {
+                keep[j] = lo + j < hi ? hist16[(size_t)(lo + j) * stride16 + bin] : (unsigned short)0;
+                sum += keep[j];
+            }
+        } else {
+            for (int b = lo; b < hi; b++)
+                sum += hist16[(size_t)b * stride16 + bin];
+        }
+    }
     s_seg[seg][bl] = sum;
     __syncthreads();
     unsigned run = 0;
     for (int k = 0; k < seg; k++)
         run += s_seg[k][bl];
     if (bin < nbins) {
-        for (int b = lo; b < hi; b++) {
-            unsigned v = hist16[(size_t)b * stride16 + bin];
-            prefix[(size_t)b * nbins + bin] = run;
-            run += v;
+        if (kept) {
+#pragma unroll
+            for (int j = 0; j < kKeep; j++)
+                if (lo + j < hi) {
+                    prefix[(size_t)(lo + j) * nbins + bin] = run;
+                    run += keep[j];
+                }
+        } else {
+            for (int b = lo; b < hi; b++) {
+                unsigned v = hist16[(size_t)b * stride16 + bin];
+                prefix[(size_t)b * nbins + bin] = run;
+                run += v;
+            }
         }
     }
     if (seg == kScanSegs - 1) {  // lanes 992..1023: one half-wave holds the totals of the group's 32 bins
