@@ -68,6 +68,14 @@ def parse():
                     help="snapshots in flight per GPU: consecutive steps alternate between this many handles, each on "
                          "its own HIP stream (kernels of different steps may then run concurrently)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
+    ap.add_argument("--reduce-algo", default="rooted", choices=["rooted", "rs_gather", "p2p"],
+                    help="--shard files: the per-plane rank sum as one library reduce per map (rooted), as reduce-scatter "
+                         "+ gather of the slices (rs_gather), or as the same direct pattern written with sends / receives "
+                         "and local sums (p2p); slicer_amd/parallel.py")
+    ap.add_argument("--reduce-layout", default="auto", choices=["auto", "on", "off"],
+                    help="after the main layout, also time the reference's own layout in the same run -- sub-files split "
+                         "over the ranks + the per-plane RCCL sum to rank 0 (slicer-v2.cpp:162-175, 214-217) -- and report "
+                         "it as config.reduce_layout (auto: when N > 1 and the main layout is another one)")
     ap.add_argument("--cpu-baseline", dest="cpu", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--cpu-particles", type=int, default=1 << 24, help="particles per CPU-baseline worker file")
     ap.add_argument("--cpu-cores", type=int, default=0)
@@ -260,177 +268,197 @@ def main():
     if a.planes == 1:
         lds, ld2s = [3.0], [3.25]
     ptype = 0 if a.hydro else 1
-
-    reduce_steps = shard == "files" and use_dist
-    gather_steps = shard == "steps" and use_dist
-    overlap = (reduce_steps or gather_steps) and not a.no_overlap
-    # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and workspace
-    # and works on its own stream; RCCL runs on torch.distributed's communication stream.
-    n_handles = 2 if overlap else 1
-    n_handles = max(n_handles, a.streams)
+    npix2 = a.npix * a.npix
     chunk = per_file
     if os.environ.get("SLICER_BENCH_CHUNK_LOG2"):  # experiment: several kernel passes per sub-file
         chunk = min(per_file, 1 << int(os.environ["SLICER_BENCH_CHUNK_LOG2"]))
-    handles = [slicer_amd.Slicer(local_rank, max_chunk=chunk) for _ in range(n_handles)]
-    streams = ([torch.cuda.Stream() for _ in range(n_handles)] if n_handles > 1 else [torch.cuda.current_stream()])
-    for S, st in zip(handles, streams):
-        S.set_stream(st.cuda_stream)
-    S0 = handles[0]
 
-    # which sub-files of which snapshots this rank deposits
-    my_snaps = list(range(a.snapshots))
-    if shard == "snapshots":
-        seed0 = SEED + 1000 * rank          # every rank owns different boxes
-        my_files = list(range(files))
-    elif shard == "steps":
-        seed0 = SEED                        # same boxes everywhere; a rank builds whole steps, all sub-files
-        my_files = list(range(files))
-    else:
-        seed0 = SEED                        # same boxes everywhere, sub-files split as slicer-v2.cpp:162-175
-        lo, hi = parallel.file_range(files, world, rank)
-        my_files = list(range(lo, hi))
-
-    # resident raw POS blocks: [snapshot][file] -> torch buffer (HBM)
+    # resident raw POS blocks: [snapshot][file] -> torch buffer (HBM).  Every rank keeps every sub-file of its boxes:
+    # the same boxes on all ranks (layouts "steps" and "files", which pick their sub-files out of them) or boxes of its
+    # own ("snapshots").
+    seed0 = SEED + (1000 * rank if shard == "snapshots" else 0)
+    gen = slicer_amd.Slicer(local_rank, max_chunk=chunk)
+    gen.set_stream(torch.cuda.current_stream().cuda_stream)
     pos = []
-    with torch.cuda.stream(streams[0]):
-        for s in my_snaps:
-            row = []
-            for ff in my_files:
-                buf = torch.empty(per_file * 3, dtype=torch.float32, device="cuda")
-                S0.synth_positions(buf.data_ptr(), ff * per_file, per_file, BOX, seed=seed0 + s, clustered=a.clustered)
-                row.append(buf)
-            pos.append(row)
-        masses = None
-        if a.hydro:  # one block of per-particle masses, shared by every sub-file (values in (0.5, 1.5) * MASS)
-            masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
+    for s in range(a.snapshots):
+        row = []
+        for ff in range(files):
+            buf = torch.empty(per_file * 3, dtype=torch.float32, device="cuda")
+            gen.synth_positions(buf.data_ptr(), ff * per_file, per_file, BOX, seed=seed0 + s, clustered=a.clustered)
+            row.append(buf)
+        pos.append(row)
+    masses = None
+    if a.hydro:  # one block of per-particle masses, shared by every sub-file (values in (0.5, 1.5) * MASS)
+        masses = (torch.rand(per_file, dtype=torch.float32, device="cuda") + 0.5) * MASS
     torch.cuda.synchronize()
+    gen.close()
 
-    pending = [None] * n_handles  # async rank-sum / send works of the handle's previous step
-    npix2 = a.npix * a.npix
-    G = None
-    if gather_steps:
-        G = parallel.StepGather(dist, torch, world, rank, len(lds), npix2, torch.float32, "cuda", root=0, depth=2)
-    own_count = [0]
+    class Layout:
+        """One way of spreading the job over the ranks: its handles, its step function, its timed run."""
 
-    def settle(k):
-        """Step k's rank sum has to be complete before its accumulators become f32 maps (and are reused); sends of
-        the handle's previous step have to be complete before its maps are zeroed again."""
-        if pending[k] is not None:
-            with torch.cuda.stream(streams[k]):
-                for w in pending[k]:
-                    w.wait()
-                if reduce_steps:
-                    handles[k].plane_finalize()
-            pending[k] = None
+        def __init__(self, shard, reduce_algo="rooted"):
+            self.shard, self.reduce_algo = shard, reduce_algo
+            self.reduce_steps = shard == "files" and use_dist
+            self.gather_steps = shard == "steps" and use_dist
+            self.overlap = (self.reduce_steps or self.gather_steps) and not a.no_overlap
+            # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and
+            # workspace and works on its own stream; RCCL runs on torch.distributed's communication stream.
+            self.n_handles = max(2 if self.overlap else 1, a.streams)
+            self.handles = [slicer_amd.Slicer(local_rank, max_chunk=chunk) for _ in range(self.n_handles)]
+            self.streams = ([torch.cuda.Stream() for _ in range(self.n_handles)] if self.n_handles > 1
+                            else [torch.cuda.current_stream()])
+            for S, st in zip(self.handles, self.streams):
+                S.set_stream(st.cuda_stream)
+            if shard == "files":  # sub-files split as slicer-v2.cpp:162-175
+                lo, hi = parallel.file_range(files, world, rank)
+                self.my_files = list(range(lo, hi))
+            else:                  # whole snapshots: all sub-files
+                self.my_files = list(range(files))
+            self.pending = [None] * self.n_handles  # async rank-sum / send works of the handle's previous step
+            self.G = None
+            if self.gather_steps:
+                self.G = parallel.StepGather(dist, torch, world, rank, len(lds), npix2, torch.float32, "cuda", root=0,
+                                             depth=2)
+            self.own_count = 0
 
-    def deposit(S, s):
-        S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
-        for j, ff in enumerate(my_files):
-            if a.hydro:
-                S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                             RND["center"], RND["rcase"])
-                S.deposit_device(0, pos[s][j].data_ptr(), per_file, masses.data_ptr())
-            else:
-                S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
-                             RND["center"], RND["rcase"])
-                S.deposit_device(1, pos[s][j].data_ptr(), per_file)
-            S.file_end()
+        def close(self):
+            for S in self.handles:
+                S.close()
+            self.handles = []
 
-    def local_step(i, k=0):
-        """One snapshot -> its finished plane maps on this rank, no communication."""
-        with torch.cuda.stream(streams[k]):
-            deposit(handles[k], i % len(my_snaps))
-            handles[k].plane_finalize()
+        def settle(self, k):
+            """Step k's rank sum has to be complete before its accumulators become f32 maps (and are reused); sends of
+            the handle's previous step have to be complete before its maps are zeroed again."""
+            if self.pending[k] is not None:
+                with torch.cuda.stream(self.streams[k]):
+                    if hasattr(self.pending[k], "wait"):
+                        self.pending[k].wait()
+                    else:
+                        for w in self.pending[k]:
+                            w.wait()
+                    if self.reduce_steps:
+                        self.handles[k].plane_finalize()
+                self.pending[k] = None
 
-    def step(i):
-        s = i % len(my_snaps)
-        if gather_steps:
-            if G.owner(i) == rank:  # this rank builds the whole step; the root gets the maps
-                k = own_count[0] % n_handles
-                own_count[0] += 1
-                settle(k)
-                with torch.cuda.stream(streams[k]):
-                    deposit(handles[k], s)
-                    handles[k].plane_finalize()
-                    if rank != 0:
-                        maps = [parallel.device_tensor(torch, handles[k].plane_device_maps(p)[0], npix2)
-                                for p in range(len(lds))]
-                        pending[k] = G.send(i, maps)
-                        if not overlap:
-                            settle(k)
-            elif rank == 0:
-                G.expect(i)  # (waits for the ring slot's previous occupant first)
-                if not overlap:
-                    G.complete(i)
-            return
-        k = i % n_handles
-        S = handles[k]
-        settle(k)
-        with torch.cuda.stream(streams[k]):
-            deposit(S, s)
-            if reduce_steps:
-                # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL over xGMI, on the accumulators
-                # (f32 / f64 / fixed point), converted to f32 maps once, after the sum
-                if overlap:
-                    pending[k] = parallel.reduce_planes(S, dist, torch, root=0, async_op=True)
+        def deposit(self, S, s):
+            S.plane_begin(a.npix, FOV, lds, ld2s, mas=mas, accum=accum, algo=algo, want_type_maps=False, hydro=a.hydro)
+            for ff in self.my_files:
+                if a.hydro:
+                    S.file_begin([per_file, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                                 RND["center"], RND["rcase"])
+                    S.deposit_device(0, pos[s][ff].data_ptr(), per_file, masses.data_ptr())
                 else:
-                    parallel.reduce_planes(S, dist, torch, root=0)
+                    S.file_begin([0, per_file, 0, 0, 0, 0], [0, MASS, 0, 0, 0, 0], BOX, RND["sgn"], RND["face"],
+                                 RND["center"], RND["rcase"])
+                    S.deposit_device(1, pos[s][ff].data_ptr(), per_file)
+                S.file_end()
+
+        def local_step(self, i, k=0):
+            """One snapshot -> its finished plane maps on this rank, no communication."""
+            with torch.cuda.stream(self.streams[k]):
+                self.deposit(self.handles[k], i % a.snapshots)
+                self.handles[k].plane_finalize()
+
+        def step(self, i):
+            s = i % a.snapshots
+            G = self.G
+            if self.gather_steps:
+                if G.owner(i) == rank:  # this rank builds the whole step; the root gets the maps
+                    k = self.own_count % self.n_handles
+                    self.own_count += 1
+                    self.settle(k)
+                    with torch.cuda.stream(self.streams[k]):
+                        self.deposit(self.handles[k], s)
+                        self.handles[k].plane_finalize()
+                        if rank != 0:
+                            maps = [parallel.device_tensor(torch, self.handles[k].plane_device_maps(p)[0], npix2)
+                                    for p in range(len(lds))]
+                            self.pending[k] = G.send(i, maps)
+                            if not self.overlap:
+                                self.settle(k)
+                elif rank == 0:
+                    G.expect(i)  # (waits for the ring slot's previous occupant first)
+                    if not self.overlap:
+                        G.complete(i)
+                return
+            k = i % self.n_handles
+            S = self.handles[k]
+            self.settle(k)
+            with torch.cuda.stream(self.streams[k]):
+                self.deposit(S, s)
+                if self.reduce_steps:
+                    # slicer-v2.cpp:214: MPI_Reduce(mapxytot, SUM, root 0) per plane -> RCCL over xGMI, on the
+                    # accumulators (f32 / f64 / fixed point), converted to f32 maps once, after the sum
+                    if self.overlap:
+                        self.pending[k] = parallel.reduce_planes(S, dist, torch, root=0, async_op=True,
+                                                                 algo=self.reduce_algo)
+                    else:
+                        parallel.reduce_planes(S, dist, torch, root=0, algo=self.reduce_algo)
+                else:
+                    S.plane_finalize()
+
+        def drain(self):
+            for k in range(self.n_handles):
+                self.settle(k)
+            if self.G is not None:
+                self.G.finish()
+
+        def run(self):
+            """Counts, warm-up, the timed K steps (barrier + synchronize on both sides, max over ranks)."""
+            # deposits per step (identical for a given snapshot every time it is processed); with --shard files the
+            # counters on rank 0 are the rank sums (reduced with the maps)
+            dep_per_snap = []
+            for s in range(a.snapshots):
+                if self.gather_steps:
+                    self.local_step(s)  # every rank learns the counts of every snapshot (outside the timed region)
+                else:
+                    self.step(s)
+                    self.drain()
+                dep_per_snap.append(sum(int(_counts(self.handles[0 if self.gather_steps else s % self.n_handles], p)[ptype])
+                                        for p in range(len(lds))))
+            self.algo_mask = self.handles[0].algo_mask()
+            for i in range(a.warmup):
+                self.step(i)
+            self.drain()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                self.step(i)
+            self.drain()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+
+            my_dep = sum(dep_per_snap[i % a.snapshots] for i in range(a.steps))
+            my_in = a.steps * per_file * len(self.my_files)
+            if use_dist:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if self.gather_steps:  # the K steps are the job, whichever rank built them: my_dep / my_in are the totals
+                tot_dep, tot_in = float(my_dep), float(my_in)
+            elif use_dist:
+                # --shard files: rank 0's counters already hold the sums over ranks; the others' are partial
+                c = torch.tensor([my_dep if (not self.reduce_steps or rank == 0) else 0, my_in], dtype=torch.float64,
+                                 device="cuda")
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                tot_dep, tot_in = float(c[0].item()), float(c[1].item())
             else:
-                S.plane_finalize()
+                tot_dep, tot_in = float(my_dep), float(my_in)
+            self.my_dep = my_dep
+            return dt, tot_dep, tot_in
 
-    def drain():
-        for k in range(n_handles):
-            settle(k)
-        if G is not None:
-            G.finish()
-
-    # deposits per step (identical for a given snapshot every time it is processed); with --shard files the counters
-    # on rank 0 are the rank sums (reduced with the maps)
-    dep_per_snap = []
-    for s in range(len(my_snaps)):
-        if gather_steps:
-            local_step(s)  # every rank learns the counts of every snapshot (outside the timed region)
-        else:
-            step(s)
-            drain()
-        dep_per_snap.append(sum(int(_counts(handles[0 if gather_steps else s % n_handles], p)[ptype])
-                                for p in range(len(lds))))
-    algo_mask = S0.algo_mask()
-
-    for i in range(a.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    my_dep = sum(dep_per_snap[i % len(my_snaps)] for i in range(a.steps))
-    my_in = a.steps * per_file * len(my_files)
-    if gather_steps:  # the K steps are the job, whichever rank built them: my_dep / my_in already are the totals
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot_dep, tot_in = float(my_dep), float(my_in)
-    elif use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # --shard files: rank 0's counters already hold the sums over ranks; the others' are partial -> take rank 0's
-        c = torch.tensor([my_dep if (not reduce_steps or rank == 0) else 0, my_in], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot_dep, tot_in = float(c[0].item()), float(c[1].item())
-    else:
-        tot_dep, tot_in = float(my_dep), float(my_in)
+    L = Layout(shard, a.reduce_algo)
+    dt, tot_dep, tot_in = L.run()
+    reduce_steps, gather_steps, overlap = L.reduce_steps, L.gather_steps, L.overlap
+    n_handles, handles, my_files, my_dep, algo_mask = L.n_handles, L.handles, L.my_files, L.my_dep, L.algo_mask
+    S0 = handles[0]
+    step, local_step, drain = L.step, L.local_step, L.drain
 
     # per-kernel durations, live, with HIP events on the launch stream (a few extra untimed steps)
     S0.profile_reset()
@@ -504,6 +532,29 @@ def main():
     if rank == 0 and world == 1 and (a.e2e == "on" or (a.e2e == "auto" and a.cpu != "off")):
         e2e = end_to_end(a)
 
+    # ---- the reference's own multi-rank layout in the same run: sub-files of every snapshot split over
+    # the ranks (slicer-v2.cpp:162-175) + the per-plane sum to rank 0 over RCCL (slicer-v2.cpp:214-217), timed with the
+    # library's rooted reduce and with the direct reduce-scatter + gather-to-root, on the same boxes
+    reduce_layout = None
+    want_reduce_layout = a.reduce_layout == "on" or (a.reduce_layout == "auto" and world > 1)
+    if use_dist and want_reduce_layout and shard != "files":
+        L.close()
+        reduce_layout = {}
+        for ralgo in ("rooted", "p2p"):
+            try:
+                L2 = Layout("files", ralgo)
+                dt2, dep2, in2 = L2.run()
+                reduce_layout[ralgo] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2, "n_in_per_s": in2 / dt2,
+                                        "overlap": L2.overlap}
+                L2.close()
+            except Exception as e:  # the main number must survive a failing secondary layout
+                reduce_layout[ralgo] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        reduce_layout["what"] = ("--shard files: every snapshot's sub-files in contiguous ranges over the ranks "
+                                 "(slicer-v2.cpp:162-175) + per-plane sum to rank 0 in the accumulator type over RCCL "
+                                 "(slicer-v2.cpp:214-217); rooted = one library reduce per map, p2p = direct "
+                                 "reduce-scatter + gather-to-root as grouped sends / receives (slicer_amd/parallel.py); "
+                                 "same boxes, steps and timing protocol as `value`")
+
     if rank == 0:
         out = {
             "metric": "particles/s deposited (TSC, 4096^2 map)" if (a.mas == "tsc" and a.npix == 4096)
@@ -524,6 +575,8 @@ def main():
                             f"resident in HBM, {a.npix}^2 {a.mas.upper()}, {len(lds)} lens planes per pass, "
                             f"{'clustered' if a.clustered else 'uniform'}",
                 "shard": shard, "algo": a.algo, "accum": a.accum, "algo_mask": algo_mask,
+                "reduce_algo": a.reduce_algo if reduce_steps else None,
+                "reduce_layout": reduce_layout,
                 "collective": (("per-plane sum to rank 0 in the accumulator type over RCCL, " if reduce_steps else
                                 "finished plane maps sent to rank 0 point to point over RCCL, ")
                                + ("overlapped with the following steps" if overlap else "not overlapped"))
@@ -544,8 +597,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    for S in handles:
-        S.close()
+    L.close()
     if use_dist:
         dist.destroy_process_group()
 
@@ -572,6 +624,17 @@ def end_to_end(a):
         if r.returncode or len(ms) < 2:
             return {"error": f"adapter_driver rc={r.returncode}"}
         best = min(ms[1:])
+        # the same call when the caller does not keep per-type planes (partinplanes = 0) and opts out of the six
+        # per-type maps it would discard (slicer_amd_adapter_skip_type_maps): half the device-to-host traffic
+        skip = None
+        envs = dict(env, SLICER_AMD_SKIP_TYPE_MAPS="1", ADAPTER_PARTINPLANES="0")
+        rs = subprocess.run([drv, base, "0", "1", str(a.npix), str(FOV), "3.0", "3.25", "3.0", "0", "0",
+                             os.path.join(d, "ms.bin")], capture_output=True, env=envs, text=True, timeout=300)
+        mss = [float(ln.split(": ")[1].split()[0]) for ln in rs.stderr.splitlines() if ln.startswith("createDensityMaps call")]
+        if rs.returncode == 0 and len(mss) >= 2:
+            bs = min(mss[1:])
+            skip = {"ms_per_call": bs, "value": n / (bs * 1e-3), "pcie_frac": 12.0 * n / (bs * 1e-3) / PCIE_PEAK,
+                    "what": "partinplanes = 0 with slicer_amd_adapter_skip_type_maps(1): all-types map only"}
         # the same sub-file for the four planes of one box replication, called plane by plane as slicer-v2.cpp does: the
         # adapter deposits all four during the first call and serves the other three from the device
         four = None
@@ -585,7 +648,7 @@ def end_to_end(a):
             four = {"calls_ms": bl, "ms_per_plane": sum(bl) / 4.0, "input_particles_per_s_per_plane": n / (sum(bl) / 4.0 * 1e-3),
                     "what": "four createDensityMaps calls (planes of one replication) on the same sub-file; best of 2 warm loops"}
         return {"value": n / (best * 1e-3), "unit": "input particles/s", "ms_per_call": best, "calls_ms": ms,
-                "four_planes": four,
+                "four_planes": four, "without_type_maps": skip,
                 "pcie_frac": 12.0 * n / (best * 1e-3) / PCIE_PEAK,
                 "what": f"page-cached format-2 file ({n} particles) -> C++ createDensityMaps (one plane, {a.npix}^2 TSC) -> "
                         "all-types map + populated per-type map in host memory; 8 read threads; best of 4 warm calls"}

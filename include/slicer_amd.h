@@ -129,6 +129,19 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out);
 int slicer_destroy(slicer_handle h);
 const char *slicer_last_error(slicer_handle h); /* valid until the next call on h; h may be NULL */
 
+/* Tuning and test knobs of a handle (integers).  The environment seeds them once, in slicer_create (SLICER_<KEY> in
+ * upper case); afterwards only this call changes them -- no launch path reads the environment, so handles driven by
+ * different host threads (SLICER_amd --devices) do not share mutable state.  Not while deposits are in flight (an
+ * open file, or chunks waiting for their tile launch: SLICER_ERR_STATE).  Keys:
+ *   k4_int       integer (u64) LDS tile cells: 0 never, 1 automatic (>= 2048 particles per bin), 2 always
+ *   tile_log2, tile_h_log2, bin_batch, unit_rows    tile / batch / unit geometry overrides (0 = automatic)
+ *   k3_per_cu    persistent sort workgroups per CU          k1_general   1: always the general project+bin kernel
+ *   k1_stack     fast project+bin kernel: -1 automatic, 0 / 1 project in place / through the wave stack
+ *   ngp_general  1: no in-tile NGP fold                      dl_quot      0: no reciprocal-product grid quotient
+ * Unknown keys return SLICER_ERR_ARG. */
+int slicer_set_option(slicer_handle h, const char *key, int32_t value);
+int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
+
 /* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = handle-owned. */
 int slicer_set_stream(slicer_handle h, void *hip_stream);
 
@@ -166,7 +179,7 @@ int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
  * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0); bits 4 / 5 tell which project+bin kernel the
  * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip); bit 6: a tile
  * kernel launch kept its tiles as integer (u64) cells (constant-mass TSC, F32 / F64 accumulators, enough records per
- * tile; SLICER_K4_INT=0 / 2 in the environment forbids / forces them -- a tuning and test knob). */
+ * tile; option k4_int = 0 / 2 forbids / forces them -- a tuning and test knob). */
 int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
 /* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
  * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */
@@ -196,6 +209,13 @@ typedef struct {
 int slicer_plane_flush(slicer_handle h);
 int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m);
 int slicer_reduce_meta_set(slicer_handle h, const slicer_reduce_meta *m);
+/* The same sequence without a host synchronisation (slicer_reduce_meta_get waits for the deposits in order to read the
+ * negativity guard, which stalls a pipelined caller once per plane pass): _get_async fills in only what the host knows
+ * (live accumulators, scales; v[21] = 0) and the caller combines the guard on the device instead -- one MAX all-reduce
+ * of the int32 at *d_flag (slicer_plane_device_guard), issued with the map sums; slicer_plane_status /
+ * slicer_plane_read then report a guard raised on any rank. */
+int slicer_reduce_meta_get_async(slicer_handle h, slicer_reduce_meta *m);
+int slicer_plane_device_guard(slicer_handle h, int32_t **d_flag);
 /* acc[s] (s as above; NULL when not live), element kind SLICER_ELEM_* (one kind per pass), npix^2 elements each. */
 int slicer_plane_accumulators(slicer_handle h, int plane, void **acc /* [7] */, int32_t *elem_kind);
 

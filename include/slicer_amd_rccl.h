@@ -39,6 +39,17 @@ const char *slicer_rccl_last_error(void);
  * (want_type_maps).  Counters of selected particles are summed too (the reference forgets to). */
 int slicer_rccl_plane_reduce(slicer_handle h, slicer_rccl_comm c, int root, int per_type);
 
+/* The same sum with the algorithm chosen by the caller (an argument, not an environment variable):
+ *   SLICER_RCCL_REDUCE_ROOTED  one ncclReduce per map (what slicer_rccl_plane_reduce does): RCCL's ring / tree
+ *   SLICER_RCCL_REDUCE_DIRECT  SURVEY S5: in-place ncclReduceScatter (rank j ends up with the sum of slice j of every
+ *                              map) + ncclSend / ncclRecv of the slices to the root, grouped per plane.  xGMI links
+ *                              are point to point, so 1/N of a map per link and hop instead of the whole map through
+ *                              every link of a ring.  Any map size (the n % N tail goes through a small rooted reduce).
+ * Sums run in the accumulator type with both, so a FIXED64 result does not depend on the choice. */
+#define SLICER_RCCL_REDUCE_ROOTED 0
+#define SLICER_RCCL_REDUCE_DIRECT 1
+int slicer_rccl_plane_reduce_ex(slicer_handle h, slicer_rccl_comm c, int root, int algo);
+
 #ifdef __cplusplus
 }
 #endif

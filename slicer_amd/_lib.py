@@ -40,6 +40,8 @@ SYMBOLS = {
     "slicer_create": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_H)]),
     "slicer_destroy": (C.c_int, [_H]),
     "slicer_last_error": (C.c_char_p, [_H]),
+    "slicer_set_option": (C.c_int, [_H, C.c_char_p, C.c_int32]),
+    "slicer_get_option": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int32)]),
     "slicer_set_stream": (C.c_int, [_H, C.c_void_p]),
     "slicer_plane_begin": (C.c_int, [_H, C.POINTER(PlaneDesc)]),
     "slicer_file_begin": (C.c_int, [_H, C.POINTER(FileDesc)]),
@@ -59,6 +61,8 @@ SYMBOLS = {
     "slicer_plane_flush": (C.c_int, [_H]),
     "slicer_reduce_meta_get": (C.c_int, [_H, C.POINTER(ReduceMeta)]),
     "slicer_reduce_meta_set": (C.c_int, [_H, C.POINTER(ReduceMeta)]),
+    "slicer_reduce_meta_get_async": (C.c_int, [_H, C.POINTER(ReduceMeta)]),
+    "slicer_plane_device_guard": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "slicer_plane_accumulators": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "slicer_device_malloc": (C.c_int, [_H, C.c_size_t, C.POINTER(C.c_void_p)]),
     "slicer_device_free": (C.c_int, [_H, C.c_void_p]),

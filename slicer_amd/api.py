@@ -119,6 +119,17 @@ class Slicer:
         if rc:
             raise SlicerError(rc, (_L.slicer_last_error(self._h) or b"").decode())
 
+    def set_option(self, key, value):
+        """Tuning / test knob of this handle (include/slicer_amd.h: slicer_set_option); returns the previous value."""
+        old = self.get_option(key)
+        self._chk(_L.slicer_set_option(self._h, key.encode(), int(value)))
+        return old
+
+    def get_option(self, key):
+        v = C.c_int32(0)
+        self._chk(_L.slicer_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def set_stream(self, stream_ptr):
         self._chk(_L.slicer_set_stream(self._h, C.c_void_p(stream_ptr)))
 
@@ -191,6 +202,23 @@ class Slicer:
         m = _lib.ReduceMeta()
         self._chk(_L.slicer_reduce_meta_get(self._h, C.byref(m)))
         return [int(x) for x in m.v]
+
+    def reduce_meta_get_async(self):
+        """reduce_meta_get without the host synchronisation: the guard entry stays 0; combine the device flag of
+        plane_device_guard() across ranks instead (parallel.reduce_planes does)."""
+        m = _lib.ReduceMeta()
+        self._chk(_L.slicer_reduce_meta_get_async(self._h, C.byref(m)))
+        return [int(x) for x in m.v]
+
+    def plane_device_guard(self):
+        p = C.c_void_p()
+        self._chk(_L.slicer_plane_device_guard(self._h, C.byref(p)))
+        return p.value
+
+    def get_stream(self):
+        p = C.c_void_p()
+        self._chk(_L.slicer_get_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def reduce_meta_set(self, ints):
         m = _lib.ReduceMeta()

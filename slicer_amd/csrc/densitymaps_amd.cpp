@@ -28,7 +28,7 @@ struct PlaneGroup {
     unsigned ffmin = 0, ffmax = 0;
     double fov = 0;
     float rcase = 0;
-    int npix = 0, hydro = 0, mas = 0, accum = 0;
+    int npix = 0, hydro = 0, mas = 0, accum = 0, skip_types = 0;
 };
 
 struct AdapterState {
@@ -36,6 +36,7 @@ struct AdapterState {
     int device = -1;
     int mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32, algo = SLICER_ALGO_AUTO, true_counts = 0;
     int want_device = -1;
+    int skip_type_maps = -1;  // -1: SLICER_AMD_SKIP_TYPE_MAPS from the environment (default 0)
     PlaneGroup grp;
 };
 AdapterState g;
@@ -79,6 +80,8 @@ extern "C" void slicer_amd_adapter_config(int mas, int accum, int algo, int true
     g.true_counts = true_counts;
     g.want_device = device;
 }
+
+extern "C" void slicer_amd_adapter_skip_type_maps(int on) { g.skip_type_maps = on ? 1 : 0; }
 
 extern "C" void slicer_amd_adapter_shutdown(void)
 {
@@ -124,6 +127,13 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
     if (!ensure_handle(myid))
         return 1;
     slicer_handle h = g.h;
+    // Opt-in (slicer_amd_adapter_skip_type_maps / SLICER_AMD_SKIP_TYPE_MAPS=1): without partinplanes the caller never
+    // reads mapxytoti (writeMaps, densitymaps.cpp:537-584, only writes the all-types map), so the per-type maps are
+    // neither built on the device nor copied back -- they come back zero-filled; mapxytot is unchanged in the TSC
+    // accumulator's tolerance (one shared accumulator instead of the f32 sum of six) and bitwise under NGP.
+    if (g.skip_type_maps < 0)
+        g.skip_type_maps = env_int("SLICER_AMD_SKIP_TYPE_MAPS", 0) ? 1 : 0;
+    const int skip_types = (g.skip_type_maps && !p.partinplanes) ? 1 : 0;
 
     // a plane left on the device by the pass of an earlier call (see PlaneGroup)?
     PlaneGroup &G = g.grp;
@@ -131,7 +141,8 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
     bool made_group = false;
     const bool hit = G.valid && isnap > G.first && isnap < G.first + G.n && !G.used[isnap - G.first] && G.file == File &&
                      G.ffmin == ffmin && G.ffmax == ffmax && G.fov == fovradiants && G.rcase == (float)rcase &&
-                     G.npix == p.npix && G.hydro == (p.hydro ? 1 : 0) && G.mas == g.mas && G.accum == g.accum;
+                     G.npix == p.npix && G.hydro == (p.hydro ? 1 : 0) && G.mas == g.mas && G.accum == g.accum &&
+                     G.skip_types == skip_types;
     if (hit) {
         slot = isnap - G.first;
         G.used[slot] = true;
@@ -159,7 +170,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
         d.algo = g.algo;
         d.hydro = p.hydro ? 1 : 0;
         d.snopt = p.snopt;
-        d.want_type_maps = 1;
+        d.want_type_maps = skip_types ? 0 : 1;
         d.fov_rad = fovradiants;
         for (int j = 0; j < n; j++) {
             d.ld[j] = lens.ld[isnap + j];
@@ -185,6 +196,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
             G.hydro = p.hydro ? 1 : 0;
             G.mas = g.mas;
             G.accum = g.accum;
+            G.skip_types = skip_types;
         }
     }
 
@@ -279,7 +291,7 @@ int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, uns
         return 1;
     }
     float *d_toti[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (slicer_plane_device_maps(h, slot, nullptr, d_toti) != SLICER_OK) {
+    if (!skip_types && slicer_plane_device_maps(h, slot, nullptr, d_toti) != SLICER_OK) {
         std::cerr << "slicer_amd: " << slicer_last_error(h) << std::endl;
         return 1;
     }

@@ -14,6 +14,10 @@
 // true_counts: 0 keeps ntotxyi at 0 exactly like the reference (its inner array shadows the
 // out-parameter, densitymaps.cpp:497); 1 returns the real selected counts.  device < 0: myid % #GPUs.
 extern "C" void slicer_amd_adapter_config(int mas, int accum, int algo, int true_counts, int device);
+// on != 0: when InputParams.partinplanes is false, do not build or copy back the six per-type maps -- the reference's
+// caller discards them then (writeMaps, densitymaps.cpp:537-584, writes mapxytot only); mapxytoti comes back
+// zero-filled.  Halves the device-to-host traffic of a call.  Default off: all seven maps, as the reference fills them.
+extern "C" void slicer_amd_adapter_skip_type_maps(int on);
 extern "C" void slicer_amd_adapter_shutdown(void);
 
 int createDensityMaps(InputParams &p, Lens &lens, Random &random, int isnap, unsigned int ffmin, unsigned int ffmax,

@@ -49,9 +49,12 @@ std::vector<double> transverseDistanceTable(const Cosmology &c, const std::vecto
         const double omegaK = 1.0 - c.omegaM - c.omegaLambda;
         if (fabs(omegaK) < 1e-5) {
             out[i] = radial;
-        } else {  // curved: D_M = R sin(D_C / R) or R sinh(D_C / R), R = c / (H0 sqrt|Omega_K|)
-            const double R = kC / c.h0 / sqrt(fabs(omegaK));
-            out[i] = omegaK < 0 ? R * sinh(radial / R) : R * sin(radial / R);
+        } else {
+            // curved: the reference's expression in its own operation order (w0waCDM.cpp:75,79 -- including its choice
+            // of sinh for Omega_K < 0), so that the roundings, and with them the plane edges, are the same
+            const double rootK = sqrt(fabs(omegaK));
+            out[i] = omegaK < 0 ? kC / c.h0 / rootK * sinh(rootK * c.h0 / kC * radial)
+                                : kC / c.h0 / rootK * sin(rootK * c.h0 / kC * radial);
         }
     }
     return out;
@@ -115,9 +118,9 @@ int readInput(InputParams &p, const string &name)
 {
     std::ifstream fin(name.c_str());
     if (!fin.is_open()) {
-        cerr << " Params file " << name << " does not exist where you are running the code " << endl;
-        cerr << " I will STOP here!!! " << endl;
-        return 1;  // the reference calls exit(1) here
+        cerr << "slicer_amd: cannot open the parameter file '" << name << "' (path relative to the working directory)"
+             << endl;
+        return 1;  // data.cpp:15-18 stops the program here; this driver returns the error instead
     }
     string str;
     auto next = [&](string &dst) {
@@ -214,20 +217,21 @@ void testHydro(InputParams &p, const Header &data)
 }
 
 // ---------------------------------------------------------------- densitymaps.cpp:9-33
+// Index of the snapshot nearest to `dlens` in comoving distance (-1 for an empty list).  Behaviour kept from the
+// reference: the distance gap is rounded to binary32 before it is compared, the first of equal gaps wins, and a list
+// whose every snapshot is 99999 Mpc/h or further away answers 0.
 int getSnap(vector<double> &zsnap, const NaturalCubicSpline &GetDl, double dlens)
 {
-    if (zsnap.empty())
-        return -1;
-    unsigned int pos = 0;
-    double aux = 99999;
-    for (size_t i = 0; i < zsnap.size(); i++) {
-        float test = (float)std::abs(GetDl.eval(zsnap[i]) - dlens);  // the reference stores |.| in a float
-        if (test < aux) {
-            aux = test;
-            pos = (unsigned)i;
+    int nearest = zsnap.empty() ? -1 : 0;
+    double smallest = 99999;
+    for (int k = 0; k < (int)zsnap.size(); k++) {
+        const float gap = (float)fabs(GetDl.eval(zsnap[k]) - dlens);
+        if (gap < smallest) {
+            smallest = gap;
+            nearest = k;
         }
     }
-    return (int)pos;
+    return nearest;
 }
 
 // ---------------------------------------------------------------- densitymaps.cpp:46-156

@@ -784,8 +784,12 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 {
     using acc_t = typename AccT<ACC>::type;
     using lds_t = typename AccT<ACC>::lds;
-    extern __shared__ unsigned char smem_raw[];
+    // 16-byte aligned by declaration: ds_add_u64 / ds_add_f64 on a cell that is only 4-byte aligned FAULTS (round 2: a
+    // static __shared__ array in front of an unaligned dynamic array did exactly that).  The attribute makes the
+    // compiler pad whatever static LDS precedes the dynamic segment; the small tables of this kernel live behind the tile.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     lds_t *tile = reinterpret_cast<lds_t *>(smem_raw);
+    static_assert(alignof(lds_t) <= 16 && sizeof(lds_t) <= 8, "tile cells are 4- or 8-byte scalars");
 
     unsigned bin = blockIdx.x, part = 0;
     if (blockIdx.x >= (unsigned)G.nbins) {
@@ -937,7 +941,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         __syncthreads();
     }
 
-    // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics)
+    // flush: consecutive lanes -> consecutive pixels of one map row (shaped atomics).  (Round 3 measured the alternative
+    // for the cells only this workgroup adds to -- plain load + add + store, stores running at ~6 TB/s against ~1.3 TB/s
+    // of added bytes for memory-side float atomics: tile kernel 471 -> 873 us.  The atomics are fire-and-forget, the
+    // read-modify-write puts an HBM round trip per cell row on the flushing wave.)
     auto flush = [&](int row, int col) {
         const lds_t v = tile[row * W + col];
         const int px = x0 - 1 + col, py = y0 - 1 + row;
@@ -1038,7 +1045,7 @@ size_t tile_items_bytes(const BinGeom &G, uint64_t total_particles)
 
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
                                const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,
-                               uint64_t total_particles, bool *int_cells_used, hipStream_t s)
+                               uint64_t total_particles, int int_mode, bool *int_cells_used, hipStream_t s)
 {
     *int_cells_used = false;
     // total_particles bounds the number of records (each particle emits at most one on this path).  Workspace:
@@ -1059,13 +1066,11 @@ hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const 
         }
         return launch_k4<kNGP, kF32>(pow2, cfg.has_mass, P, G, L, T, I, F, max_items, s);
     }
-    // constant-mass TSC in the F32 / F64 modes: integer tile cells (SLICER_K4_INT=0 keeps the f64 cells, =2 forces the
-    // integer ones).  They pay where the records dominate (2048^2 x 4 planes, 65536 particles per bin: 370 against 622 us);
+    // constant-mass TSC in the F32 / F64 modes: integer tile cells (int_mode, the handle's option k4_int: 0 keeps the
+    // f64 cells, 2 forces the integer ones).  They pay where the records dominate (2048^2 x 4 planes, 65536 particles per bin: 370 against 622 us);
     // a launch with few records per tile is mostly tile zeroing and flushing, where the u64 -> float conversion of every
     // cell costs what the cheaper LDS atomic saves (8192^2 x 4 planes, 4096 per bin: 1242 against 1205 us; 2048 per bin:
     // equal) -- below 2048 particles per bin the f64 cells stay.
-    const char *env_int = getenv("SLICER_K4_INT");
-    const int int_mode = env_int ? atoi(env_int) : 1;
     const bool int_cells = int_mode == 2 || (int_mode == 1 && total_particles / (uint64_t)G.nbins >= 2048);
     if (int_cells && (cfg.acc == kF32 || cfg.acc == kF64)) {
         if (cfg.has_mass) {  // the quantum follows the largest mass the sort kernel saw (TileQuantum)

@@ -42,8 +42,41 @@ enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SC
 
 }  // namespace
 
+// Tuning and test knobs of one handle.  Read from the environment ONCE, in slicer_create (so that the tools/ scripts
+// keep working), and changed per handle through slicer_set_option -- never getenv on a launch path: the per-GPU host
+// threads of SLICER_amd --devices run concurrently.
+struct Options {
+    int k4_int = 1;       // integer tile cells: 0 never, 1 when a launch has >= 2048 particles per bin, 2 always
+    int tile_log2 = 0;    // log2 tile width (0 = automatic); tile_h_log2 likewise for the height (0 = tile_log2)
+    int tile_h_log2 = 0;
+    int bin_batch = 0;    // particles per project+bin workgroup (0 = automatic)
+    int unit_rows = 0;    // tile rows per unit (0 = automatic): band units on small maps, for tests
+    int k3_per_cu = 2;    // persistent sort workgroups per CU
+    int k1_general = 0;   // 1: always the general project+bin kernel
+    int k1_stack = -1;    // fast project+bin kernel: compact survivors through the wave stack (0 / 1; -1 = by slab depth)
+    int ngp_general = 0;  // 1: no in-tile NGP fold (count map + k_fold_ngp)
+    int dl_quot = 1;      // maps that are not a power of two wide: allow the swept reciprocal-product quotient
+};
+struct OptionName {
+    const char *key, *env;
+    int Options::*field;
+};
+const OptionName kOptionNames[] = {
+    {"k4_int", "SLICER_K4_INT", &Options::k4_int},
+    {"tile_log2", "SLICER_TILE_LOG2", &Options::tile_log2},
+    {"tile_h_log2", "SLICER_TILE_H_LOG2", &Options::tile_h_log2},
+    {"bin_batch", "SLICER_BIN_BATCH", &Options::bin_batch},
+    {"unit_rows", "SLICER_UNIT_ROWS", &Options::unit_rows},
+    {"k3_per_cu", "SLICER_K3_PER_CU", &Options::k3_per_cu},
+    {"k1_general", "SLICER_K1_GENERAL", &Options::k1_general},
+    {"k1_stack", "SLICER_K1_STACK", &Options::k1_stack},
+    {"ngp_general", "SLICER_NGP_GENERAL", &Options::ngp_general},
+    {"dl_quot", "SLICER_DL_QUOT", &Options::dl_quot},
+};
+
 struct slicer_handle_s {
     int device = 0;
+    Options opt;
     int num_cus = 256;
     unsigned items_epoch = 0;  // launches of the tile kernel on the current w_items workspace
     hipStream_t stream = nullptr;
@@ -59,7 +92,9 @@ struct slicer_handle_s {
     PlaneBufs planes[SLICER_MAX_PLANES];
     unsigned long long *d_counts = nullptr;  // [SLICER_MAX_PLANES][6]
     int *d_neg = nullptr;
-    unsigned *d_maxmass = nullptr;  // [6] bits of the largest selected per-particle mass per species (this pass)
+    // [7] bits of the largest selected per-particle mass of this pass: per species, and slot 6 for the shared accumulator
+    // (want_type_maps == 0), whose pending list mixes species -- the tile kernel's quantum must cover all of them
+    unsigned *d_maxmass = nullptr;
     bool type_seen[6] = {};       // in this plane pass
     bool shared_seen = false;
     int algo_mask = 0;            // bit (1 << SLICER_ALGO_*) of every algorithm that ran in this pass; bit 3 = thinning
@@ -441,7 +476,7 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
         T.nsel[p] = h->d_counts + (size_t)p * 6 + type;
     }
     T.neg_flag = h->d_neg;
-    T.max_mass = h->d_maxmass + type;
+    T.max_mass = h->d_maxmass + (shared ? 6 : type);
 }
 
 constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
@@ -450,7 +485,7 @@ constexpr int kUnitBins = 8192;   // up to this many bins the units are whole pl
 // Tile geometry of the binned path.  Tiles are powers of two so that pixel -> tile is a shift.  4-byte
 // LDS cells (NGP counts): up to 128 x 128 (+halo = 67.6 KiB of LDS, two workgroups per CU); 8-byte: 64 x 128.
 // Small maps get smaller tiles so that the grid still has >= ~1024 workgroups.
-bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
+bool choose_geom(const slicer_plane_desc &d, int acc, const Options &opt, BinGeom &G)
 {
     int nrmax = 0;
     for (int p = 0; p < d.n_planes; p++)
@@ -462,9 +497,9 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
         for (int q = p + 1; q < d.n_planes; q++)
             if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
                 return false;
-    // tuning / test knobs, read on every call so that a test can flip them inside one process
-    const int env_s = env_int("SLICER_TILE_LOG2"), env_h = env_int("SLICER_TILE_H_LOG2");
-    const int env_b = env_int("SLICER_BIN_BATCH");
+    // tuning / test knobs of the handle (slicer_set_option)
+    const int env_s = opt.tile_log2, env_h = opt.tile_h_log2;
+    const int env_b = opt.bin_batch;
     const bool wide = acc != kCountU32;  // every mode but the NGP counts keeps 8-byte cells in LDS
     int s = 7;  // log2 tile side
     auto tiles = [&](int sl) {
@@ -482,7 +517,7 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     G.ntx = (d.npix + (1 << G.tw_log2) - 1) >> G.tw_log2;
     G.nty = (d.npix + (1 << G.th_log2) - 1) >> G.th_log2;
     // units: whole planes while everything fits kUnitBins tiles, otherwise bands of tile rows (large maps)
-    const int env_rows = env_int("SLICER_UNIT_ROWS");  // tests
+    const int env_rows = opt.unit_rows;  // tests
     const long tiles_plane = (long)G.ntx * G.nty;
     if (tiles_plane * d.n_planes <= kUnitBins && !env_rows) {
         G.units_per_plane = 1;
@@ -500,7 +535,7 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
     if (G.n_units > kMaxUnits || G.tiles_per_unit > 8192 || nb > kMaxBins)
         return false;
     G.nbins = (int)nb;
-    // tuning overrides (SLICER_TILE_LOG2 / SLICER_TILE_H_LOG2 / SLICER_BIN_BATCH): the batch must keep every
+    // tuning overrides (tile_log2 / tile_h_log2 / bin_batch): the batch must keep every
     // workgroup's first particle 16-byte aligned (multiple of 4; kept at a multiple of 1024) and fit the 16-bit
     // per-workgroup counters
     G.batch = env_b ? std::min(std::max((env_b / 1024) * 1024, 1024), 64512) : kBinBatch;
@@ -512,11 +547,10 @@ bool choose_geom(const slicer_plane_desc &d, int acc, BinGeom &G)
 }
 
 // persistent K3 workgroups: two per CU (their LDS and registers allow it), so that one workgroup's load / LDS /
-// store phases overlap the other's; SLICER_K3_PER_CU overrides (tuning knob)
+// store phases overlap the other's; option k3_per_cu overrides (tuning knob)
 static int scatter_workgroups(slicer_handle h)
 {
-    const int per_cu = std::max(1, env_int("SLICER_K3_PER_CU", 2));
-    return h->num_cus * per_cu;
+    return h->num_cus * std::max(1, h->opt.k3_per_cu);
 }
 
 int run_box_sweep(slicer_handle h, double box, unsigned out[9])
@@ -550,7 +584,7 @@ int box_quotient_ok(slicer_handle h, double box, bool &ok)
 }
 
 // Maps that are not a power of two wide: may the grid arithmetic use quot_dl3 instead of f64 divisions by dl = 1/npix?
-// One exhaustive device sweep (2^30 operands, ~1 ms) per distinct npix and handle, cached.  SLICER_DL_QUOT=0 says no.
+// One exhaustive device sweep (2^30 operands, ~1 ms) per distinct npix and handle, cached.  Option dl_quot = 0 says no.
 int dl_quotient_ok(slicer_handle h, int npix, bool &ok, unsigned *examples9 = nullptr)
 {
     if (!examples9)
@@ -575,12 +609,12 @@ int dl_quotient_ok(slicer_handle h, int npix, bool &ok, unsigned *examples9 = nu
 }
 
 // Kernel arguments of k_project_bin_fast and whether this (file, pass) qualifies for it; see the conditions in
-// slicer_project_bin.hip.  SLICER_K1_GENERAL=1 forces the general kernel (tests run both).
+// slicer_project_bin.hip.  Option k1_general = 1 forces the general kernel (tests run both).
 int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nblocks, K1Args &A, bool &fast)
 {
     memset(&A, 0, sizeof A);
     fast = false;
-    if (env_int("SLICER_K1_GENERAL") || P.n_planes > 4 || !(P.lim < 1.5) || G.region != G.batch ||
+    if (h->opt.k1_general || P.n_planes > 4 || !(P.lim < 1.5) || G.region != G.batch ||
         (uint64_t)G.n_units * (uint64_t)nblocks * (uint64_t)G.region >= (1ull << 31))
         return SLICER_OK;
     for (int p = 0; p < P.n_planes; p++)
@@ -623,12 +657,11 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
     A.n_planes = P.n_planes;
     {
         // expected fraction of particles that reach the projection: the slabs' share of the unit box depth
-        // (positions are uniform in z to first order); SLICER_K1_STACK=0/1 overrides
+        // (positions are uniform in z to first order); option k1_stack = 0 / 1 overrides
         double depth = 0;
         for (int p = 0; p < P.n_planes; p++)
             depth += std::max(0.0, std::min<double>(P.zhi[p], P.rcase + 1.0) - std::max<double>(P.zlo[p], P.rcase));
-        const int env = env_int("SLICER_K1_STACK", -1);
-        A.stack = env >= 0 ? env : (depth < 0.6 ? 1 : 0);
+        A.stack = h->opt.k1_stack >= 0 ? h->opt.k1_stack : (depth < 0.6 ? 1 : 0);
     }
     for (int p = 0; p < 4; p++)
         A.zlo[p] = P.zlo[p];  // +inf beyond n_planes (make_params)
@@ -684,7 +717,7 @@ bool ngp_foldable(slicer_handle h, int type)
     int species = 0;
     for (int t = 0; t < 6; t++)
         species += h->file.npart[t] > 0;
-    return species == 1 && h->file.npart[type] > 0 && !h->file_partial_flush[type] && !env_int("SLICER_NGP_GENERAL");
+    return species == 1 && h->file.npart[type] > 0 && !h->file_partial_flush[type] && !h->opt.ngp_general;
 }
 
 // NGP: some of the open file's records of this species are (about to be) in the global count map, so none of them may
@@ -733,7 +766,7 @@ int flush_group(slicer_handle h, int group)
         ProfScope ps(h, KN_TILE);
         bool int_cells = false;
         HIPCHK(h, launch_tile_deposit(Q.cfg, Q.P, Q.G, Q.L, Q.T, F, h->w_items.p, h->items_epoch++, Q.particles,
-                                      &int_cells, h->stream));
+                                      h->opt.k4_int, &int_cells, h->stream));
         if (int_cells)
             h->algo_mask |= 1 << 6;
     }
@@ -879,7 +912,7 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
     auto &Q = h->pg[group];
     const slicer_plane_desc &d = h->desc;
     const bool has_mass = d_mass != nullptr;
-    if (!getenv("SLICER_BIN_BATCH")) {
+    if (!h->opt.bin_batch) {
         // K1 keeps two workgroups per CU resident: size the batch so that the workgroups of this call fill whole
         // rounds of resident slots instead of leaving a short tail round
         const uint64_t slots = 2ull * (uint64_t)h->num_cus;
@@ -986,7 +1019,7 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
             sub.ld2[j] = d.ld2[p0 + j];
             sub.nrepperp[j] = d.nrepperp[p0 + j];
         }
-        return choose_geom(sub, cfg.acc, Gs) && scatter_lds_bytes(Gs, has_mass) <= 160 * 1024 - 256;
+        return choose_geom(sub, cfg.acc, h->opt, Gs) && scatter_lds_bytes(Gs, has_mass) <= 160 * 1024 - 256;
     };
     bool binned = d.algo != SLICER_ALGO_DIRECT && fits(0, d.n_planes, G);
     if (!binned && d.algo != SLICER_ALGO_DIRECT)
@@ -1141,12 +1174,14 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
     if (!h)
         return fail(nullptr, SLICER_ERR_NOMEM, "out of host memory");
     h->device = device;
+    for (const OptionName &o : kOptionNames)  // the environment seeds the knobs once; slicer_set_option changes them
+        h->opt.*(o.field) = env_int(o.env, h->opt.*(o.field));
     // record cursors are 32-bit: one kernel pass carries at most 2^30 particles
     h->max_chunk = max_chunk ? std::min<uint64_t>(max_chunk, 1ull << 30) : (1ull << 24);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->own) != hipSuccess ||
         hipMalloc((void **)&h->d_counts, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6) != hipSuccess ||
         hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->d_maxmass, 6 * sizeof(unsigned)) != hipSuccess) {
+        hipMalloc((void **)&h->d_maxmass, 7 * sizeof(unsigned)) != hipSuccess) {
         int rc = fail(nullptr, SLICER_ERR_HIP, "device %d initialisation failed: %s", device,
                       hipGetErrorString(hipGetLastError()));
         delete h;
@@ -1203,6 +1238,37 @@ int slicer_destroy(slicer_handle h)
     return SLICER_OK;
 }
 
+int slicer_set_option(slicer_handle h, const char *key, int32_t value)
+{
+    if (!h || !key)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    // (a pass stays "open" until the next slicer_plane_begin so that its maps can be read; what must not see a knob
+    // change is work in flight: an open file, or binned chunks still waiting for their tile launch)
+    bool busy = h->in_file;
+    for (auto &Q : h->pg)
+        busy = busy || Q.L.n > 0;
+    if (busy)
+        return fail(h, SLICER_ERR_STATE, "slicer_set_option with deposits in flight (open file or pending chunks)");
+    for (const OptionName &o : kOptionNames)
+        if (!strcmp(o.key, key)) {
+            h->opt.*(o.field) = value;
+            return SLICER_OK;
+        }
+    return fail(h, SLICER_ERR_ARG, "unknown option '%s'", key);
+}
+
+int slicer_get_option(slicer_handle h, const char *key, int32_t *value)
+{
+    if (!h || !key || !value)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    for (const OptionName &o : kOptionNames)
+        if (!strcmp(o.key, key)) {
+            *value = h->opt.*(o.field);
+            return SLICER_OK;
+        }
+    return fail(h, SLICER_ERR_ARG, "unknown option '%s'", key);
+}
+
 int slicer_set_stream(slicer_handle h, void *hip_stream)
 {
     if (!h)
@@ -1235,7 +1301,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     HIPCHK(h, hipSetDevice(h->device));
     h->desc = *desc;
     h->dl_quot_ok = false;
-    if (!is_pow2(desc->npix) && env_int("SLICER_DL_QUOT", 1)) {
+    if (!is_pow2(desc->npix) && h->opt.dl_quot) {
         int rcq = dl_quotient_ok(h, desc->npix, h->dl_quot_ok);
         if (rcq)
             return rcq;
@@ -1271,7 +1337,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     }
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_neg, 0, sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_maxmass, 0, 6 * sizeof(unsigned), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_maxmass, 0, 7 * sizeof(unsigned), h->stream));
     return SLICER_OK;
 }
 
@@ -1598,12 +1664,14 @@ void reduce_slots(slicer_handle h, bool live[7], int &elem)
 }
 }  // namespace
 
-int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m)
+namespace {
+// the host-known part of the reduce meta: which accumulators are live and their FIXED64 scales (v[21..23] = 0)
+int reduce_meta_local(slicer_handle h, slicer_reduce_meta *m, const char *who)
 {
     if (!h || !m)
         return fail(h, SLICER_ERR_ARG, "null argument");
     if (!h->in_plane || h->in_file || h->finalized)
-        return fail(h, SLICER_ERR_STATE, "slicer_reduce_meta_get: after the last slicer_file_end, before finalize");
+        return fail(h, SLICER_ERR_STATE, "%s: after the last slicer_file_end, before finalize", who);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = thin_replay(h);
     if (!rc)
@@ -1620,11 +1688,33 @@ int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m)
         m->v[7 + s] = fx ? e : INT32_MIN;
         m->v[14 + s] = fx ? -e : INT32_MIN;
     }
+    m->v[21] = m->v[22] = m->v[23] = 0;
+    return SLICER_OK;
+}
+}  // namespace
+
+int slicer_reduce_meta_get(slicer_handle h, slicer_reduce_meta *m)
+{
+    int rc = reduce_meta_local(h, m, "slicer_reduce_meta_get");
+    if (rc)
+        return rc;
     int neg = 0;
     HIPCHK(h, hipMemcpyAsync(&neg, h->d_neg, sizeof neg, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     m->v[21] = neg ? 1 : 0;
-    m->v[22] = m->v[23] = 0;
+    return SLICER_OK;
+}
+
+int slicer_reduce_meta_get_async(slicer_handle h, slicer_reduce_meta *m)
+{
+    return reduce_meta_local(h, m, "slicer_reduce_meta_get_async");
+}
+
+int slicer_plane_device_guard(slicer_handle h, int32_t **d_flag)
+{
+    if (!h || !d_flag)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    *d_flag = (int32_t *)h->d_neg;
     return SLICER_OK;
 }
 

@@ -188,6 +188,6 @@ struct NgpFold {
 };
 hipError_t launch_tile_deposit(const LaunchCfg &cfg, const PassParams &P, const BinGeom &G, const PendingList &L,
                                const Targets &T, const NgpFold &F, void *items_ws, unsigned epoch,
-                               uint64_t total_particles, bool *int_cells_used, hipStream_t s);
+                               uint64_t total_particles, int int_mode, bool *int_cells_used, hipStream_t s);
 
 }  // namespace slicer

@@ -10,12 +10,17 @@
 //     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
 //   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
 //     partinplanes runs write their per-type files;                                      --reference-counts disables
-//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass.
+//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass and one device
+//     (the thinning deviates come from the process-global libc rand() stream, densitymaps.cpp:387-397: the reference's
+//     MPI ranks each own an identically seeded copy of it, host threads of one process would interleave their draws).
 #include <dlfcn.h>
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -120,7 +125,7 @@ struct RcclApi {
     void *lib = nullptr;
     int (*init_all)(slicer_rccl_comm *, int, const int *) = nullptr;
     int (*destroy)(slicer_rccl_comm) = nullptr;
-    int (*plane_reduce)(slicer_handle, slicer_rccl_comm, int, int) = nullptr;
+    int (*plane_reduce)(slicer_handle, slicer_rccl_comm, int, int) = nullptr;  // slicer_rccl_plane_reduce_ex
     const char *(*last_error)(void) = nullptr;
     bool load()
     {
@@ -131,9 +136,38 @@ struct RcclApi {
         }
         init_all = (decltype(init_all))dlsym(lib, "slicer_rccl_comm_init_all");
         destroy = (decltype(destroy))dlsym(lib, "slicer_rccl_comm_destroy");
-        plane_reduce = (decltype(plane_reduce))dlsym(lib, "slicer_rccl_plane_reduce");
+        plane_reduce = (decltype(plane_reduce))dlsym(lib, "slicer_rccl_plane_reduce_ex");
         last_error = (decltype(last_error))dlsym(lib, "slicer_rccl_last_error");
         return init_all && destroy && plane_reduce && last_error;
+    }
+};
+
+// All rank threads meet here after their deposits and learn whether any of them failed: a collective is entered by
+// every rank or by none (a rank that skipped it alone would leave the others waiting in RCCL for ever; the reference
+// calls MPI_Abort in that situation, slicer-v2.cpp:204-207).
+class Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int n, waiting = 0, generation = 0;
+    bool failed = false, verdict = false;
+
+public:
+    explicit Rendezvous(int n_) : n(n_) {}
+    bool any_failed(bool mine)  // blocks until all n ranks have called; the same answer for all of them
+    {
+        std::unique_lock<std::mutex> lk(m);
+        failed = failed || mine;
+        const int gen = generation;
+        if (++waiting == n) {
+            verdict = failed;
+            failed = false;
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+        return verdict;
     }
 };
 
@@ -230,7 +264,7 @@ int host_plane_reduce(vector<Rank> &ranks, int npix, int n_planes)
 
 int main(int argc, char **argv)
 {
-    string inifile, plan_path, devices_spec, reduce_mode = "rccl";
+    string inifile, plan_path, devices_spec, reduce_mode = "rccl", reduce_algo = "rooted";
     int device = 0, mas = SLICER_MAS_TSC, accum = SLICER_ACC_F32;
     bool plan_only = false, single_plane = false, reference_counts = false, replication = false;
     for (int i = 1; i < argc; i++) {
@@ -238,6 +272,7 @@ int main(int argc, char **argv)
         if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--devices" && i + 1 < argc) devices_spec = argv[++i];
         else if (a == "--reduce" && i + 1 < argc) reduce_mode = argv[++i];  // rccl (default) | host
+        else if (a == "--reduce-algo" && i + 1 < argc) reduce_algo = argv[++i];  // rooted (default) | direct
         else if (a == "--ngp") mas = SLICER_MAS_NGP;
         else if (a == "--accum" && i + 1 < argc) {
             string v = argv[++i];
@@ -321,10 +356,19 @@ int main(int argc, char **argv)
         single_plane = true;  // thinning consumes libc rand() plane by plane (densitymaps.cpp:387-397)
 
     vector<int> devs = devices_spec.empty() ? vector<int>{device} : parse_devices(devices_spec);
-    if (devs.empty() || (reduce_mode != "rccl" && reduce_mode != "host")) {
-        cerr << "bad --devices / --reduce" << endl;
+    if (devs.empty() || (reduce_mode != "rccl" && reduce_mode != "host") ||
+        (reduce_algo != "rooted" && reduce_algo != "direct")) {
+        cerr << "bad --devices / --reduce / --reduce-algo" << endl;
         return 2;
     }
+    if (p.snopt != 0 && devs.size() > 1) {
+        cerr << "snopt > 0 needs a single device: the shot-noise thinning draws from the process-global libc rand() "
+                "stream in selection order (densitymaps.cpp:387-397); the reference's MPI ranks each own an identically "
+                "seeded copy of that stream, the rank threads of this process would interleave their draws and no two "
+                "runs would agree" << endl;
+        return 2;
+    }
+    const int rccl_algo = reduce_algo == "direct" ? SLICER_RCCL_REDUCE_DIRECT : SLICER_RCCL_REDUCE_ROOTED;
     vector<Rank> ranks(devs.size());
     for (size_t r = 0; r < devs.size(); r++) {
         ranks[r].device = devs[r];
@@ -345,6 +389,7 @@ int main(int argc, char **argv)
             ranks[r].comm = comms[r];
     }
     slicer_handle h = ranks[0].h;  // device 0 of the list is the root: it ends up with the sums and writes the maps
+    Rendezvous rendezvous(nranks);
     cout << " Now loop on " << lens.nplanes << " planes " << endl;
     float rcase = 0.0f;  // slicer-v2.cpp:137
     int isnap = 0;
@@ -406,7 +451,7 @@ int main(int argc, char **argv)
         }
         // one rank's share of the pass: its contiguous range of sub-files (slicer-v2.cpp:162-175: numfiles / nranks each,
         // the last rank takes the remainder), then the rank sum
-        auto run_rank = [&](int r) {
+        auto deposit_rank = [&](int r) {
             Rank &R = ranks[r];
             slicer_handle hr = R.h;
             R.rc = 0;
@@ -465,9 +510,19 @@ int main(int argc, char **argv)
                 if (R.rc == 0 && slicer_file_end(hr) != SLICER_OK)
                     return failed("file_end");
             }
-            // slicer-v2.cpp:214-217: the sum over ranks onto the root, here over RCCL on the accumulators.  Every
-            // rank takes part even after a local failure would be wrong: failures abort the run below, like MPI_Abort.
-            if (R.rc == 0 && nranks > 1 && R.comm && rccl.plane_reduce(hr, R.comm, 0, 0) != SLICER_OK) {
+        };
+        auto run_rank = [&](int r) {
+            deposit_rank(r);
+            Rank &R = ranks[r];
+            // slicer-v2.cpp:214-217: the sum over ranks onto the root, here over RCCL on the accumulators.  The ranks
+            // agree on the outcome of the deposit phase first: the collective is entered by all of them or by none.
+            if (nranks > 1 && rendezvous.any_failed(R.rc != 0)) {
+                if (R.rc == 0)
+                    cerr << "slicer_amd (device " << R.device << "): another rank failed; skipping the rank sum" << endl;
+                R.rc = 1;
+                return;
+            }
+            if (R.rc == 0 && nranks > 1 && R.comm && rccl.plane_reduce(R.h, R.comm, 0, rccl_algo) != SLICER_OK) {
                 cerr << "slicer_amd (device " << R.device << "): rank sum: " << rccl.last_error() << endl;
                 R.rc = 1;
             }

@@ -44,35 +44,177 @@ def combine_meta(dist, torch, meta, on_device):
     return [int(x) for x in t.tolist()]
 
 
-def reduce_planes(S, dist, torch, root=0, per_type=None, async_op=False, finalize=True):
+REDUCE_ALGOS = ("rooted", "rs_gather", "p2p")
+
+
+def _slices(n, world):
+    """Slice j of an n-element accumulator: [j * q, (j + 1) * q), the last one also takes the n % world tail."""
+    q = n // world
+    return [(j * q, (j + 1) * q if j < world - 1 else n) for j in range(world)]
+
+
+class _Works:
+    """Pending communication of one reduce_planes call: `wait()` completes it (stages run in order)."""
+
+    def __init__(self):
+        self.stages = []
+
+    def add(self, works, then=None):
+        self.stages.append(([w for w in works if w is not None], then))
+
+    def wait(self):
+        for works, then in self.stages:
+            for w in works:
+                w.wait()
+            if then is not None:
+                then()
+        self.stages = []
+
+
+def _sum_rooted(dist, t, root, async_op):
+    """slicer-v2.cpp:214: one rooted sum, left to the library (RCCL: a ring or tree over xGMI)."""
+    return [dist.reduce(t, dst=root, op=dist.ReduceOp.SUM, async_op=async_op)], None
+
+
+def _sum_rs_gather(dist, t, root, async_op, world, rank):
+    """reduce-scatter (every rank ends up with the sum of its own 1/N slice) + the slices gathered on
+    the root -- with point-to-point xGMI links each slice crosses one link per hop instead of the whole map crossing
+    every link of a ring.  RCCL's reduce_scatter; the tail n % N goes through a small rooted reduce."""
+    n = t.numel()
+    q = n // world
+    works = []
+    if q:
+        body = t[:q * world]
+        works.append(dist.reduce_scatter_tensor(body[rank * q:(rank + 1) * q], body, op=dist.ReduceOp.SUM,
+                                                async_op=async_op))
+        works.append(dist.gather(body[rank * q:(rank + 1) * q],
+                                 [body[j * q:(j + 1) * q] for j in range(world)] if rank == root else None, dst=root,
+                                 async_op=async_op))
+    if n - q * world:
+        works.append(dist.reduce(t[q * world:], dst=root, op=dist.ReduceOp.SUM, async_op=async_op))
+    return works, None
+
+
+def _sum_p2p(dist, torch, t, root, world, rank, tag0):
+    """The direct form written out with sends and receives (works on every backend; the gloo rehearsal of the tests
+    runs it): rank r sends slice j to rank j for every j != r -- one message per dedicated link --, adds the N - 1
+    slices it receives to its own, and the reduced slices then travel to the root.  Every exchange is one
+    batch_isend_irecv (a grouped RCCL send/recv: sends and receives of a pair progress together, no ordering deadlock).
+    Returns (works, then): `then` runs after the works (local sums) and returns the second hop's works."""
+    n = t.numel()
+    sl = _slices(n, world)
+    lo, hi = sl[rank]
+    tmp = {}
+    ops = []
+    for j in range(world):
+        if j == rank:
+            continue
+        if sl[j][1] > sl[j][0]:
+            ops.append(dist.P2POp(dist.isend, t[sl[j][0]:sl[j][1]], j, tag=tag0 + rank))
+        if hi > lo:
+            tmp[j] = torch.empty(hi - lo, dtype=t.dtype, device=t.device)
+            ops.append(dist.P2POp(dist.irecv, tmp[j], j, tag=tag0 + j))
+    works = dist.batch_isend_irecv(ops) if ops else []
+
+    def second_hop():
+        mine = t[lo:hi]
+        for j in sorted(tmp):  # fixed order: rank-invariant arithmetic for the f32 / f64 accumulators
+            mine += tmp[j]
+        hop = []
+        if rank == root:
+            for j in range(world):
+                if j != root and sl[j][1] > sl[j][0]:
+                    hop.append(dist.P2POp(dist.irecv, t[sl[j][0]:sl[j][1]], j, tag=tag0 + world + j))
+        elif hi > lo:
+            hop.append(dist.P2POp(dist.isend, mine, root, tag=tag0 + world + rank))
+        return dist.batch_isend_irecv(hop) if hop else []
+
+    return works, second_hop
+
+
+def reduce_planes(S, dist, torch, root=0, per_type=None, async_op=False, finalize=True, algo="rooted", sync_free=None):
     """Sum the current plane pass over the ranks onto `root`, in the accumulator's own type, then convert to f32 maps.
 
     Replaces the MPI_Reduce calls of slicer-v2.cpp:214-217.  Call after the last file_end() and INSTEAD of
     plane_finalize().  Every rank issues the same collectives even if its sub-files lack a particle type (zero-filled
     stand-ins, as the reference reduces all seven maps unconditionally); f64 / fixed-point accumulators are summed
-    before their single rounding, so a FIXED64 N-rank result is bitwise the 1-rank result.
+    before their single rounding, so a FIXED64 N-rank result is bitwise the 1-rank result (with any `algo`: integer
+    sums do not depend on the order).
     S: slicer_amd.Slicer, or any object with reduce_meta_get/set, plane_accumulators, plane_device_counts,
     plane_finalize, npix, n_planes (the gloo rehearsal in tests/ uses a host stand-in).
-    async_op=True returns the pending works without finalizing: wait on them, then call S.plane_finalize()."""
+    algo: "rooted" (one library reduce per map), "rs_gather" (reduce-scatter + gather of the slices, RCCL only) or
+    "p2p" (the same direct pattern written with sends / receives and local sums; any backend).
+    STREAMS (device backends): the handle must work on torch's CURRENT stream (S.set_stream(torch.cuda.current_stream()
+    .cuda_stream) and call this under that stream): the collectives are ordered behind the deposits -- and
+    plane_finalize behind the collectives -- through that stream; a handle on a stream of its own would race both.
+    This is checked.  async_op=True returns an object whose wait() completes the communication (call it under the same
+    stream), after which S.plane_finalize() may run.
+    sync_free (default: whenever S offers reduce_meta_get_async and the backend is a device one): no host
+    synchronisation with the deposit stream -- the reduce meta is combined from host-known entries on a side stream and
+    the negativity guard by a MAX all-reduce of the device flag next to the map sums."""
     del per_type  # the live accumulators decide (kept for source compatibility)
+    assert algo in REDUCE_ALGOS, algo
     on_device = dist.get_backend() != "gloo"
-    S.reduce_meta_set(combine_meta(dist, torch, S.reduce_meta_get(), on_device))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if on_device and hasattr(S, "get_stream"):
+        cur = int(torch.cuda.current_stream().cuda_stream)
+        if int(S.get_stream()) != cur:
+            raise RuntimeError("reduce_planes: the slicer handle does not work on torch's current stream "
+                               "(S.set_stream(torch.cuda.current_stream().cuda_stream)); its deposits and finalize "
+                               "would not be ordered with the collectives")
+    if sync_free is None:
+        sync_free = on_device and hasattr(S, "reduce_meta_get_async")
+    if sync_free:
+        meta = S.reduce_meta_get_async()
+        side = getattr(reduce_planes, "_side", None)
+        if side is None:
+            side = reduce_planes._side = torch.cuda.Stream()
+        with torch.cuda.stream(side):  # nothing of the deposit stream is waited for: host-known integers only
+            meta = combine_meta(dist, torch, meta, True)
+        S.reduce_meta_set(meta)
+    else:
+        S.reduce_meta_set(combine_meta(dist, torch, S.reduce_meta_get(), on_device))
     n = S.npix * S.npix
-    works = []
+    out = _Works()
+    first, hops = [], []
+    tag = 1 << 20
     for p in range(S.n_planes):
         acc, elem = S.plane_accumulators(p)
         for ref in acc:
-            if ref is not None:
-                works.append(dist.reduce(_as_tensor(torch, ref, n, elem), dst=root, op=dist.ReduceOp.SUM,
-                                         async_op=async_op))
+            if ref is None:
+                continue
+            t = _as_tensor(torch, ref, n, elem)
+            if algo == "rooted" or world == 1:
+                w, then = _sum_rooted(dist, t, root, async_op)
+            elif algo == "rs_gather":
+                w, then = _sum_rs_gather(dist, t, root, async_op, world, rank)
+            else:
+                w, then = _sum_p2p(dist, torch, t, root, world, rank, tag)
+                tag += 2 * world
+            first += w
+            if then is not None:
+                hops.append(then)
         cnt = S.plane_device_counts(p)
         if cnt is not None:
-            works.append(dist.reduce(_as_tensor(torch, cnt, 6, 2), dst=root, op=dist.ReduceOp.SUM, async_op=async_op))
+            first.append(dist.reduce(_as_tensor(torch, cnt, 6, 2), dst=root, op=dist.ReduceOp.SUM, async_op=async_op))
+    if sync_free:
+        flag = device_tensor(torch, S.plane_device_guard(), 1, "<i4")
+        first.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=async_op))
+    out.add(first)
+    if hops:
+        second = []
+
+        def run_hops():
+            for h in hops:
+                second.extend(h())
+        out.stages[-1] = (out.stages[-1][0], run_hops)
+        out.stages.append((second, None))  # filled in by run_hops before it is waited on
     if async_op:
-        return works
+        return out
+    out.wait()
     if finalize:
         S.plane_finalize()
-    return []
+    return out
 
 
 def reduce_host_maps(dist, torch, maps, root=0):

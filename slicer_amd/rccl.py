@@ -15,6 +15,7 @@ SYMBOLS = {
     "slicer_rccl_comm_destroy": (C.c_int, [_H]),
     "slicer_rccl_last_error": (C.c_char_p, []),
     "slicer_rccl_plane_reduce": (C.c_int, [_H, _H, C.c_int, C.c_int]),
+    "slicer_rccl_plane_reduce_ex": (C.c_int, [_H, _H, C.c_int, C.c_int]),
 }
 
 

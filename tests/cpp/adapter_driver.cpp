@@ -25,7 +25,7 @@ int main(int argc, char **argv)
     p.hydro = atoi(argv[10]) != 0;
     p.simType = "Gadget";
     p.snopt = 0;
-    p.partinplanes = true;
+    p.partinplanes = getenv("ADAPTER_PARTINPLANES") ? atoi(getenv("ADAPTER_PARTINPLANES")) != 0 : true;
     auto split = [](const char *a) {
         std::vector<double> v;
         std::string t(a);

@@ -1,0 +1,47 @@
+"""bench.py's command line on one GPU: the JSON contract, and the one-run rehearsal of BOTH multi-rank layouts
+ with a one-rank process group (SLICER_BENCH_FORCE_DIST=1: the same code path as N > 1 -- RCCL
+communicator, StepGather, reduce_planes with the sync-free reduce meta -- on a single device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--side", "128", "--npix", "1024", "--files", "2", "--snapshots", "2", "--steps", "4", "--warmup", "1",
+         "--cpu-baseline", "off", "--parity", "off", "--e2e", "off", "--profile-steps", "1"]
+
+
+def test_one_gpu_line_has_the_contract_fields():
+    d = _bench(SMALL)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["config"]["reduce_layout"] is None
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_one_run_times_the_step_layout_and_the_per_plane_reduce_layout():
+    d = _bench(SMALL + ["--shard", "steps", "--reduce-layout", "on"], env={"SLICER_BENCH_FORCE_DIST": "1",
+                                                                             "MASTER_PORT": "29533"})
+    assert d["config"]["shard"] == "steps" and d["value"] > 0
+    rl = d["config"]["reduce_layout"]
+    for algo in ("rooted", "p2p"):
+        assert "error" not in rl[algo], rl[algo]
+        assert rl[algo]["value"] > 0 and rl[algo]["ms_per_step"] > 0
+        # one rank: both layouts deposit the same particles, so the rates must be of the same order (the reduce of a
+        # one-rank group moves nothing); a sum that stalled the pipeline would show here
+        assert rl[algo]["value"] > 0.4 * d["value"], (rl[algo], d["value"])

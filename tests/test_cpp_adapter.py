@@ -30,9 +30,10 @@ def make_files(tmp_path, hydro):
     return base, files
 
 
-def run_driver(base, ffmin, ffmax, npix, fov, ld, ld2, rcase, ngp, hydro, out):
+def run_driver(base, ffmin, ffmax, npix, fov, ld, ld2, rcase, ngp, hydro, out, env=None):
     return subprocess.run([DRIVER, base, str(ffmin), str(ffmax), str(npix), repr(fov), repr(ld), repr(ld2), repr(rcase),
-                           str(int(ngp)), str(int(hydro)), out], capture_output=True, text=True, timeout=300)
+                           str(int(ngp)), str(int(hydro)), out], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, **(env or {})))
 
 
 def test_driver_is_built_and_fails_cleanly_without_input(tmp_path):
@@ -97,3 +98,34 @@ def test_adapter_deposits_the_planes_of_one_replication_in_one_pass(tmp_path):
         assert rc == 0 and nsel.sum() > 0
         assert np.array_equal(raw[0].view(np.uint32), tot.view(np.uint32))
         assert np.array_equal(raw[1:].view(np.uint32), toti.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_adapter_can_skip_the_per_type_maps_the_caller_discards(tmp_path):
+    """Without partinplanes the reference's caller never reads mapxytoti (writeMaps, densitymaps.cpp:537-584).  With the
+    opt-in switch (slicer_amd_adapter_skip_type_maps / SLICER_AMD_SKIP_TYPE_MAPS=1) the adapter neither builds nor copies
+    them: mapxytot is unchanged (bitwise under NGP, inside the TSC bar otherwise), mapxytoti reads zero.  With
+    partinplanes the switch does nothing."""
+    npix, fov, ld, ld2, rcase = 64, 0.25, 3.0, 4.0, 3.0
+    base, files = make_files(tmp_path, False)
+    for ngp in (True, False):
+        rc, tot, toti, nsel = oracle.create_density_maps(files, 0, 2, npix, False, ngp, ld, ld2, 0, fov,
+                                                         (-1, 1, -1), 3, (0.3, 0.6, 0.1), rcase)
+        assert rc == 0
+        for pip, expect_types in (("0", False), ("1", True)):
+            out = str(tmp_path / f"skip_{int(ngp)}_{pip}.bin")
+            r = run_driver(base, 0, 2, npix, fov, ld, ld2, rcase, ngp, False, out,
+                           env={"SLICER_AMD_SKIP_TYPE_MAPS": "1", "ADAPTER_PARTINPLANES": pip})
+            assert r.returncode == 0, r.stderr
+            raw = np.fromfile(out, np.float32, 7 * npix * npix).reshape(7, npix, npix)
+            if ngp:
+                assert np.array_equal(raw[0].view(np.uint32), tot.view(np.uint32))
+            else:
+                d = np.abs(raw[0].astype(np.float64) - tot.astype(np.float64))
+                assert np.all(d <= 3e-6 * tot), float(d.max())
+            if expect_types:
+                assert float(raw[2].sum()) > 0
+                if ngp:
+                    assert np.array_equal(raw[1:].view(np.uint32), toti.view(np.uint32))
+            else:
+                assert not raw[1:].any()

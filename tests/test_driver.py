@@ -21,7 +21,7 @@ EXE = os.path.join(ROOT, "slicer_amd", "SLICER_amd")
 BOX = 100000.0  # kpc/h
 
 
-def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2):
+def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0):
     snaps = [("snapdir_003/snap_003", 0.0), ("snapdir_002/snap_002", 0.1), ("snapdir_001/snap_001", 0.25)]
     files = {}
     first = 0
@@ -41,7 +41,7 @@ def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2):
     out = tmp_path / "out"
     out.mkdir()
     vals = [npix, zs, 2.0, str(tmp_path / "snapshot_list.txt"), str(tmp_path) + "/", "gadget", -229, -230, -231,
-            partinplanes, str(out) + "/cone_", "t0", 0, -1.0]
+            partinplanes, str(out) + "/cone_", "t0", snopt, -1.0]
     ini = tmp_path / "InputParams.ini"
     ini.write_text("".join(f"##### {i + 1}. #####\n{v}\n" for i, v in enumerate(vals)))
     return str(ini), files, str(out)
@@ -196,9 +196,32 @@ def test_two_rank_driver_equals_one_rank_bitwise_with_fixed64(tmp_path, partinpl
         assert np.allclose(a, b, rtol=3e-6, atol=2.0 ** -29)
 
 
+@pytest.mark.gpu
+def test_a_rank_that_fails_locally_stops_every_rank_before_the_collective(tmp_path):
+    """a rank whose deposit phase fails (here: a sub-file of its range is missing) must not leave the
+    others alone in the rank sum.  The rank threads agree on the outcome before the collective (Rendezvous,
+    slicer_main.cpp) -- none enters it, the run returns 1 at once (the reference: MPI_Abort, slicer-v2.cpp:204-207)."""
+    ini, files, out = make_cone(tmp_path)
+    os.remove(str(tmp_path / "snapdir_003/snap_003.1"))   # rank 1's only sub-file of the first snapshot
+    r = run([ini, "--devices", "0,0", "--reduce", "host"])
+    assert r.returncode == 1
+    assert "Error in opening the file" in r.stderr and "another rank failed" in r.stderr
+    assert not [f for f in os.listdir(out) if f.endswith(".fits")]
+
+
+def test_shot_noise_thinning_refuses_several_devices(tmp_path):
+    """snopt > 0 draws from the process-global libc rand() stream (densitymaps.cpp:387-397): rank threads of one process
+    would interleave their draws, so the driver refuses instead of writing maps that differ from run to run."""
+    ini, _, _ = make_cone(tmp_path, snopt=2)
+    r = run([ini, "--devices", "0,0", "--reduce", "host"])
+    assert r.returncode == 2 and "snopt > 0 needs a single device" in r.stderr
+    assert run([ini, "--plan-only", "--devices", "0,0"]).returncode == 0
+
+
 def test_driver_device_lists(tmp_path):
     ini, _, _ = make_cone(tmp_path)
     assert run([ini, "--plan-only", "--devices", "0-1"]).returncode == 0   # planning needs no device
     assert run([ini, "--devices", "0-1", "--reduce", "bogus"]).returncode == 2
+    assert run([ini, "--devices", "0-1", "--reduce-algo", "bogus"]).returncode == 2
     r = run([ini, "--devices", "0,63"])   # no such device (or no device at all here): fails loudly, nothing written
     assert r.returncode == 1 and "slicer_amd" in r.stderr

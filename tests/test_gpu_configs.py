@@ -66,10 +66,10 @@ def headline_ref():
 
 
 @pytest.mark.parametrize("accum", ["f32", "f64", "fixed64"])
-def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum, monkeypatch):
+def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum):
     # the benchmark keeps integer tile cells in the F32 / F64 modes (16384 particles per (plane, tile) bin and launch; one
     # sub-file alone sits right at the 2048 threshold): force that kernel here
-    monkeypatch.setenv("SLICER_K4_INT", "2")
+    S.set_option("k4_int", 2)
     pos, ref = headline_ref
     n = len(pos)
     d = S.to_device(pos)

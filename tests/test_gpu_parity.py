@@ -29,19 +29,41 @@ RND = dict(sgn=(-1, 1, -1), face=3, center=(0.3, 0.6, 0.1), rcase=3.0)
 U24 = 2.0 ** -24
 
 
+OPTION_KEYS = ("k4_int", "tile_log2", "tile_h_log2", "bin_batch", "unit_rows", "k3_per_cu", "k1_general", "k1_stack",
+               "ngp_general", "dl_quot")
+
+
 @pytest.fixture(scope="module")
-def S():
+def S0():
     s = slicer_amd.Slicer(0, max_chunk=1 << 20)
     yield s
     s.close()
 
 
-@pytest.fixture(autouse=True)
-def integer_tile_cells(monkeypatch):
-    """The tile kernel keeps integer (u64) LDS cells only when a launch has enough records per tile (the benchmark
-    sizes); the parity cases here are small, so force them (SLICER_K4_INT is read on every launch) -- this is the
-    path the headline configuration runs.  test_tile_cell_kind_follows_the_load checks the automatic choice."""
-    monkeypatch.setenv("SLICER_K4_INT", "2")
+@pytest.fixture
+def S(S0):
+    """The module's handle with integer tile cells forced.  The tile kernel keeps integer (u64) LDS cells only when a
+    launch has enough records per tile (the benchmark sizes); the parity cases here are small, so force them (handle
+    option k4_int, slicer_set_option) -- this is the path the headline configuration runs.  The `tile_cells` fixture
+    runs selected tests with the f64 cells too; test_tile_cell_kind_follows_the_load checks the automatic choice.
+    Every option a test changes is put back afterwards."""
+    saved = {k: S0.get_option(k) for k in OPTION_KEYS}
+    S0.set_option("k4_int", 2)
+    yield S0
+    try:
+        S0.set_option("k4_int", saved["k4_int"])
+    except slicer_amd.api.SlicerError:  # a test that failed in mid-pass left deposits in flight: a new pass drops them
+        S0.plane_begin(8, 1.0, [0.0], [1.0])
+    for k, v in saved.items():
+        S0.set_option(k, v)
+
+
+@pytest.fixture(params=[2, 0], ids=["int_cells", "f64_cells"])
+def tile_cells(request, S):
+    """Both kinds of LDS tile cells of the F32 / F64 accumulator modes: integer (u64, the benchmark's) and f64 (the
+    default below 2048 particles per bin)."""
+    S.set_option("k4_int", request.param)
+    return request.param
 
 
 def run_gpu(S, files, npix, fov, ld, ld2, ngp=False, accum=slicer_amd.ACC_F32, algo=slicer_amd.ALGO_AUTO,
@@ -70,7 +92,10 @@ def run_gpu(S, files, npix, fov, ld, ld2, ngp=False, accum=slicer_amd.ACC_F32, a
         S.file_end()
     mask = S.algo_mask()
     if algo != slicer_amd.ALGO_AUTO:
-        assert (mask & 15) in (0, 1 << algo), f"asked for algorithm {algo}, mask of what ran = {mask:#x}"
+        # the requested algorithm, and only it, ran -- nothing at all only if no particle was handed over
+        deposited = sum(int(sum(f["npart"])) for f in files)
+        want = (1 << algo) if deposited else 0
+        assert (mask & 7) == want, f"asked for algorithm {algo}, mask of what ran = {mask:#x}"
     out = [S.plane_read(p, want_types=True) for p in range(len(ld))]
     for p in ptrs:
         S.free(p)
@@ -298,7 +323,7 @@ def test_ngp_multi_file_multi_type_bit_exact(S, algo):
 @pytest.mark.parametrize("npix,n", [(64, 200000), (256, 400000), (100, 100000)])
 @pytest.mark.parametrize("accum", [slicer_amd.ACC_F32, slicer_amd.ACC_F64, slicer_amd.ACC_FIXED64])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_tsc_vs_oracle(S, npix, n, accum, algo):
+def test_tsc_vs_oracle(S, tile_cells, npix, n, accum, algo):
     files = [one_type_file(n)]
     fov, ld, ld2 = 0.25, 3.0, 3.5
     ref_tot, ref_toti, nsel = run_oracle(files, npix, fov, ld, ld2)
@@ -463,7 +488,7 @@ def test_random_configurations_binned_path(S, seed):
 
 
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_hydro_per_particle_masses_and_max_m_cap(S, algo):
+def test_hydro_per_particle_masses_and_max_m_cap(S, tile_cells, algo):
     """densitymaps.cpp:358-372: per-particle masses for massarr==0 types, > MAX_M -> 0."""
     rng = np.random.default_rng(3)
     n0, n1 = 40001, 60003
@@ -631,7 +656,7 @@ def test_heavy_tile_is_split_and_stays_exact(S):
 
 @pytest.mark.parametrize("name", __import__("golden_util").names())
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_golden_vectors(S, name, algo):
+def test_golden_vectors(S, tile_cells, name, algo):
     """The HIP path against the committed fixtures of tests/golden/ (no oracle call at run time)."""
     import golden_util
     files, c, tot, toti, nsel = golden_util.load(name)
@@ -786,11 +811,11 @@ def test_shot_noise_thinning_with_several_planes_in_one_pass(S, ngp):
 
 
 @pytest.mark.parametrize("rows", [1, 3])
-def test_band_units_layout_on_small_maps(S, rows, monkeypatch):
+def test_band_units_layout_on_small_maps(S, rows):
     """Large maps split every plane into units of a few tile rows (more than 8192 (plane, tile) bins).  The
-    SLICER_UNIT_ROWS override (read on every call) forces that layout on 512^2 / 1000^2 maps, where NGP can be compared
+    unit_rows option forces that layout on 512^2 / 1000^2 maps, where NGP can be compared
     bit for bit with the oracle and fixed-point TSC with the fused kernel; every binned run asserts that it ran binned."""
-    monkeypatch.setenv("SLICER_UNIT_ROWS", str(rows))
+    S.set_option("unit_rows", rows)
     n = 300000
     f = one_type_file(n, clustered=True)
     for npix in (512, 1000):
@@ -867,11 +892,11 @@ def test_overlapping_slabs_run_binned_plane_by_plane(S, ngp):
 
 
 @pytest.mark.parametrize("ngp", [True, False])
-def test_pass_with_too_many_bins_is_split_into_plane_groups(S, ngp, monkeypatch):
+def test_pass_with_too_many_bins_is_split_into_plane_groups(S, ngp):
     """More (plane, tile) bins than one binned pass holds (32768: four 16384^2 planes) are taken in plane groups.  An
     8 x 8 tile override (SLICER_TILE_LOG2, read on every call) produces the same situation on 1024^2 maps -- 16384
     tiles per plane, so four planes go as two groups of two -- where the oracle is quick.  Two files, two species."""
-    monkeypatch.setenv("SLICER_TILE_LOG2", "3")
+    S.set_option("tile_log2", 3)
     npix, fov = 1024, 0.25
     lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
     files, first = [], 0
@@ -968,11 +993,11 @@ def test_box_quotient_sweep(S):
 
 
 @pytest.mark.parametrize("general", [False, True])
-def test_fast_and_general_project_bin_kernels_agree(S, general, monkeypatch):
+def test_fast_and_general_project_bin_kernels_agree(S, general):
     """Both K1 variants against the oracle on the same cases: records bit-identical => NGP maps bit-exact; the variant
     that ran is read back from the algo mask (bit 4 fast, bit 5 general)."""
     if general:
-        monkeypatch.setenv("SLICER_K1_GENERAL", "1")
+        S.set_option("k1_general", 1)
     f32c = tuple(float(np.float32(c)) for c in (0.3, 0.6, 0.1))
     # (randomisation, does it qualify for the fast kernel): f32 centres do; double-precision centres and the exact 0 of
     # -DUSE_FIXED_PLC_VERTEX are left to the general kernel
@@ -996,14 +1021,43 @@ def test_fast_and_general_project_bin_kernels_agree(S, general, monkeypatch):
             assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), (rnd, p)
 
 
-def test_tile_cell_kind_follows_the_load(S, monkeypatch):
+def test_fast_project_bin_kernel_redoes_a_batch_with_too_many_exceptions(S):
+    """The fast project+bin kernel notes particles outside its domain (raw coordinate -0.0, negative, beyond the box)
+    in a 256-entry LDS list; a workgroup that sees more than that discards what it emitted and runs its WHOLE batch
+    through the exact code (slicer_project_bin.hip, `redo`).  400 such particles inside one batch (8192 particles at
+    this input size) force that branch; batches with a few exceptions and with none sit next to it.  NGP maps of all
+    four planes must be bit-exact against the oracle, and the fast kernel must be the one that ran."""
+    rng = np.random.default_rng(41)
+    pos = synth.positions(0, 300000, BOX).copy()
+    odd = rng.choice(np.arange(100, 8000), 400, replace=False)   # all inside the first batch
+    kind = rng.integers(0, 3, len(odd))
+    axis = rng.integers(0, 3, len(odd))
+    # (|excess| < 0.3 box: after the mirror, both wraps and the recentring every coordinate is back in [0, 1], so the
+    # negativity guard of densitymaps.cpp:334 stays quiet)
+    u = rng.uniform(0.01, 0.29, len(odd)).astype(np.float32)
+    for i, k, ax, uu in zip(odd, kind, axis, u):
+        pos[i, ax] = (-0.0, np.float32(BOX) * (np.float32(1) + uu), -np.float32(BOX) * uu)[k]
+    few = rng.integers(20000, 28000, 7)                     # a later batch with a handful: the epilogue list
+    pos[few, 1] = np.float32(-0.0)
+    f = dict(npart=[0, len(pos), 0, 0, 0, 0], massarr=[0, 0.0123, 0, 0, 0, 0], boxsize=BOX, pos=pos)
+    rnd = dict(RND, center=tuple(float(np.float32(c)) for c in RND["center"]))
+    lds, ld2s = [3.0, 3.25, 3.5, 3.75], [3.25, 3.5, 3.75, 4.0]
+    out = run_gpu(S, [f], 512, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
+    assert S.algo_mask() >> 4 & 3 == 1                      # bit 4: the fast kernel
+    for p in range(4):
+        ref_tot, _, nsel = run_oracle([f], 512, 0.25, lds[p], ld2s[p], ngp=True, rnd=rnd)
+        assert np.array_equal(out[p][2], nsel) and nsel[1] > 0
+        assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), p
+
+
+def test_tile_cell_kind_follows_the_load(S):
     """Integer tile cells need >= 2048 particles per (plane, tile) bin in a launch (slicer_plane_algo_mask bit 6);
     both kinds of cells give maps inside the TSC bar."""
     f = one_type_file(1 << 20)
     ref_tot, _, nsel = run_oracle([f], 512, 0.25, 3.0, 4.0)
     masks = {}
     for mode in ("0", "1", "2"):
-        monkeypatch.setenv("SLICER_K4_INT", mode)
+        S.set_option("k4_int", int(mode))
         (tot, _, cnt), = run_gpu(S, [f], 512, 0.25, [3.0], [4.0], algo=slicer_amd.ALGO_BINNED)
         masks[mode] = S.algo_mask()
         assert np.array_equal(cnt, nsel)
@@ -1012,7 +1066,7 @@ def test_tile_cell_kind_follows_the_load(S, monkeypatch):
     # automatic choice: 2^20 particles over the 2048 bins of a 512^2 map stay below 2048 per bin, over the 32 bins of a
     # 64^2 map they do not
     assert not masks["0"] & 64 and masks["2"] & 64 and not masks["1"] & 64
-    monkeypatch.setenv("SLICER_K4_INT", "1")
+    S.set_option("k4_int", 1)
     run_gpu(S, [f], 64, 0.25, [3.0], [4.0], algo=slicer_amd.ALGO_BINNED)
     assert S.algo_mask() & 64
 
@@ -1071,7 +1125,7 @@ def test_eight_planes_in_one_pass(S, ngp):
 @pytest.mark.parametrize("npix", [64, 1024])
 def test_hydro_integer_cells_with_masses_over_five_decades(S, npix):
     """Per-particle masses set the quantum of the integer tile cells by their largest value (forced here by the module's
-    SLICER_K4_INT=2): contributions of the light particles then fall below 2^-25 of that scale far more often than with
+    k4_int = 2): contributions of the light particles then fall below 2^-25 of that scale far more often than with
     one constant mass and take the side path (noted in LDS, or inline once the list is full -- the 64^2 map puts
     everything into a few tiles).  The maps must stay inside the TSC bar against the oracle."""
     n = 400000
@@ -1087,6 +1141,31 @@ def test_hydro_integer_cells_with_masses_over_five_decades(S, npix):
         assert np.array_equal(got == 0, ref == 0)
         d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
         assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref), float((d / np.maximum(ref, 1e-30)).max())
+
+
+@pytest.mark.parametrize("light_first", [True, False])
+def test_hydro_two_species_share_one_integer_cell_quantum(S, light_first):
+    """Shared accumulator (want_type_maps = 0, the driver's default without partinplanes) with per-particle masses on
+    two species 100x apart: their chunks wait in ONE pending list, so the tile kernel's integer-cell quantum has to
+    cover the heaviest selected mass of every species in the launch -- not that of the species whose chunk came first
+    (a light first species used to leave the heavy one's contributions beyond the 2^52 window of rn_scaled_u64)."""
+    n_l, n_h = 150001, 90001
+    rng = np.random.default_rng(23)
+    m_l = rng.uniform(0.001, 0.002, n_l).astype(np.float32)
+    m_h = rng.uniform(0.1, 0.2, n_h).astype(np.float32)
+    pos = synth.positions(0, n_l + n_h, BOX, clustered=True)
+    if light_first:
+        f = dict(npart=[n_l, 0, 0, 0, n_h, 0], massarr=[0.0] * 6, boxsize=BOX, pos=pos, mass={0: m_l, 4: m_h})
+    else:
+        f = dict(npart=[n_h, 0, 0, 0, n_l, 0], massarr=[0.0] * 6, boxsize=BOX, pos=pos, mass={0: m_h, 4: m_l})
+    npix = 256
+    ref_tot, _, nsel = run_oracle([f], npix, 0.25, 3.0, 4.0, hydro=True)
+    (tot, _, cnt), = run_gpu(S, [f], npix, 0.25, [3.0], [4.0], hydro=True, algo=slicer_amd.ALGO_BINNED,
+                             want_type_maps=False)
+    assert S.algo_mask() & 64 and np.array_equal(cnt, nsel)
+    assert np.array_equal(tot == 0, ref_tot == 0)
+    d = np.abs(tot.astype(np.float64) - ref_tot.astype(np.float64))
+    assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot), float((d / np.maximum(ref_tot, 1e-30)).max())
 
 
 @pytest.mark.parametrize("npix", [100, 300, 1000, 4000, 7745, 65535])

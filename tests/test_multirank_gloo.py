@@ -64,7 +64,7 @@ def _files_with_missing_species(BOX=1000.0):
     return files
 
 
-def _worker_acc(rank, world, port, q):
+def _worker_acc(rank, world, port, q, algo="rooted"):
     """reduce_planes (the code path bench.py and the C RCCL wrapper follow) on host stand-ins of the handles."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -83,7 +83,7 @@ def _worker_acc(rank, world, port, q):
                       ("ngp", False)):
         mine = HostRankPass(files[lo:hi], 32, 0.25, 3.0, 4.0, rnd, mode=mode, want_type_maps=wtm)
         had_type4 = mine.acc[4] is not None
-        parallel.reduce_planes(mine, dist, torch, root=0)
+        parallel.reduce_planes(mine, dist, torch, root=0, algo=algo)
         assert mine.finalized
         if rank == 0:
             one = HostRankPass(files, 32, 0.25, 3.0, 4.0, rnd, mode=mode, want_type_maps=wtm)
@@ -103,13 +103,14 @@ def _worker_acc(rank, world, port, q):
                 ok = ok and float(rtoti[4].sum()) > 0 and np.allclose(toti[4], rtoti[4], rtol=2e-6, atol=0)
             out[f"{mode}/{int(wtm)}"] = bool(ok)
         else:
-            out[f"{mode}/{int(wtm)}"] = (not had_type4) if wtm else True  # rank 1 really lacked the species
+            # rank 1 really lacked the species (with 2 or 3 ranks type 4 lives in rank 0's range only)
+            out[f"{mode}/{int(wtm)}"] = (not had_type4) if wtm else True
     # the negativity guard of any rank reaches the root
     bad = dict(npart=[0, 4, 0, 0, 0, 0], massarr=[0, 0.25, 0, 0, 0, 0], boxsize=1000.0,
                pos=np.full((4, 3), 2600.0 if rank == 1 else 500.0, np.float32))
     g = HostRankPass([bad], 32, 0.25, 3.0, 4.0, dict(sgn=(-1, -1, -1), face=1, center=(0., 0., 0.), rcase=0.0),
                      mode="f32")
-    parallel.reduce_planes(g, dist, torch, root=0)
+    parallel.reduce_planes(g, dist, torch, root=0, algo=algo)
     out["neg"] = bool(g.neg_remote) and (g.neg == (1 if rank == 1 else 0))
     dist.barrier()
     q.put((rank, out))
@@ -117,21 +118,24 @@ def _worker_acc(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_accumulator_typed_reduce_with_a_species_missing_on_one_rank():
+@pytest.mark.parametrize("world,algo", [(2, "rooted"), (2, "p2p"), (3, "p2p")])
+def test_two_rank_accumulator_typed_reduce_with_a_species_missing_on_one_rank(world, algo):
     """Rank-invariant collective set (no deadlock when rank 1's sub-files lack type 4), sums in the accumulator type
-    (FIXED64 2-rank == 1-rank bitwise), selected-particle counters summed, negativity guard propagated."""
+    (FIXED64 N-rank == 1-rank bitwise), selected-particle counters summed, negativity guard propagated -- with the
+    rooted library reduce and with the direct reduce-scatter + gather-to-root written as sends / receives (SURVEY S5;
+    three ranks: the 1024-pixel maps do not divide evenly, the last slice takes the tail)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_acc, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_acc, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=240) for _ in range(2))
+    res = dict(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r in (0, 1):
+    for r in range(world):
         assert all(res[r].values()), (r, res[r])
 
 
