@@ -138,6 +138,7 @@ const char *slicer_last_error(slicer_handle h); /* valid until the next call on 
  *   k3_per_cu    persistent sort workgroups per CU          k1_general   1: always the general project+bin kernel
  *   k1_stack     fast project+bin kernel: -1 automatic, 0 / 1 project in place / through the wave stack
  *   ngp_general  1: no in-tile NGP fold                      dl_quot      0: no reciprocal-product grid quotient
+ *   sort2        1: the two-level sort wherever a pass qualifies (default 0: the one-level sort)
  * Unknown keys return SLICER_ERR_ARG. */
 int slicer_set_option(slicer_handle h, const char *key, int32_t value);
 int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
@@ -179,7 +180,8 @@ int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
  * (1 << value), bit 3 = the shot-noise thinning kernels (snopt > 0); bits 4 / 5 tell which project+bin kernel the
  * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip); bit 6: a tile
  * kernel launch kept its tiles as integer (u64) cells (constant-mass TSC, F32 / F64 accumulators, enough records per
- * tile; option k4_int = 0 / 2 forbids / forces them -- a tuning and test knob). */
+ * tile; option k4_int = 0 / 2 forbids / forces them -- a tuning and test knob); bit 7: a chunk went through the two-level
+ * sort (project+bin kernel sorts by coarse bin in LDS, k_sort2 by tile; option sort2 = 1 allows it). */
 int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
 /* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
  * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */

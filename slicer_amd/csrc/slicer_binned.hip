@@ -349,6 +349,222 @@ __global__ __launch_bounds__(kSortBlock, SLICER_K3_WAVES) void k_bin_scatter(con
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3': second level of the two-level sort
+// ---------------------------------------------------------------------------------------------
+// The project+bin kernel (SORT2) leaves, per workgroup, sub-batches of records sorted by unit (coarse bin) with a table
+// of where each unit's run starts.  One work item here = (unit, group of slots_per_group sub-batch slots = 16
+// project+bin workgroups): it gathers the unit's runs of those sub-batches (contiguous pieces of ~0.5 KB), sorts the
+// ~6000 records by tile-in-unit in LDS (counting sort over <= 256 tiles) and writes them as ONE contiguous piece of
+// sxy, tile after tile, plus the item's row of ptab (where each tile's run starts).  Pieces are allocated with one
+// atomic add per item; the tile kernel finds a tile's runs through ptab (build_run_table).  No global histogram, no
+// prefix matrix, every store a run of >= ~0.4 KB.
+constexpr int kS2Block = 512;
+constexpr int kS2Cap = 8192;  // records sorted at a time (the LDS staging area); larger items take several windows
+constexpr int kS2R = kS2Cap / kS2Block;
+constexpr int kS2MaxMine = 64;  // items one persistent workgroup may have to take (host: nitems <= 64 * workgroups)
+
+template <bool POW2>
+__device__ __forceinline__ unsigned sort2_tile_of(float2 r, const PassParams &P, const BinGeom &G)
+{
+    const int nn = P.nn;
+    int gx = grid_index<POW2>(r.x, P), gy = grid_index<POW2>(r.y, P);
+    gx = min(max(gx, 0), nn - 1);  // (border-ring entries were binned with the clamped cell)
+    gy = min(max(gy, 0), nn - 1);
+    const unsigned ty = (unsigned)(gy >> G.th_log2), tx = (unsigned)(gx >> G.tw_log2);
+    return (ty % (unsigned)G.rows_per_unit) * (unsigned)G.ntx + tx;
+}
+
+template <bool POW2>
+__global__ __launch_bounds__(kS2Block, 4) void k_sort2(const float2 *__restrict__ c1, const unsigned *__restrict__ sb_off,
+                                                       const unsigned short *__restrict__ sb_start,
+                                                       const unsigned *__restrict__ sb_n, int nblocks, int slots_per_group,
+                                                       int ngroups, BinGeom G, PassParams P, float2 *__restrict__ sxy,
+                                                       unsigned *__restrict__ ptab, const unsigned *__restrict__ item_tot,
+                                                       unsigned *tile_tot)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
+    const int S = slots_per_group, ntc = G.tiles_per_unit;
+    float2 *stage = reinterpret_cast<float2 *>(smem_s2);                      // [kS2Cap] records in sorted order
+    unsigned char *scol = reinterpret_cast<unsigned char *>(stage + kS2Cap);  // [kS2Cap] tile-in-unit of stage[i]
+    unsigned *r_src = reinterpret_cast<unsigned *>(scol + kS2Cap);            // [S] first record of run r in c1
+    unsigned *r_off = r_src + S;                                              // [S + 1] runs concatenated: start of run r
+    unsigned *cnt = r_off + S + 1;                                            // [ntc] records per tile (this window)
+    unsigned *pos = cnt + ntc;                                                // [ntc] running sorted position (window)
+    unsigned *adj = pos + ntc;  // [ntc] global position of the tile's first record of this window minus its sorted start
+    unsigned *cur = adj + ntc;  // [ntc] records of the tile already written (+ its start inside the item)
+    unsigned short *first = reinterpret_cast<unsigned short *>(cur + ntc);  // [kS2Cap / 64] run of the window's record 64 c
+    __shared__ unsigned s_wave[kS2Block / 64];
+    __shared__ unsigned s_mybase[kS2MaxMine];
+    const int tid = threadIdx.x;
+    const int nslots = nblocks * kSubBatches;
+    const int nitems = G.n_units * ngroups;
+    // Where this workgroup's items go in sxy: the exclusive prefix of the item totals (summed by the project+bin kernel),
+    // in item order -- every workgroup scans the (<= 8192) totals once for itself; no allocation atomics, and the layout
+    // of sxy does not depend on the order in which the items are processed.
+    {
+        const int per = (nitems + kS2Block - 1) / kS2Block;
+        unsigned sum = 0;
+        for (int j = 0; j < per; j++) {
+            const int idx = tid * per + j;
+            sum += idx < nitems ? item_tot[idx] : 0u;
+        }
+        unsigned e = block_exclusive_scan(sum, s_wave);
+        for (int j = 0; j < per; j++) {
+            const int idx = tid * per + j;
+            if (idx < nitems) {
+                const int rel = idx - (int)blockIdx.x;
+                if (rel >= 0 && rel % (int)gridDim.x == 0)
+                    s_mybase[rel / (int)gridDim.x] = e;
+                e += item_tot[idx];
+            }
+        }
+        lds_barrier();
+    }
+    // this thread's run of item `it`: (length, first record in c1); requested one item ahead, so that the two dependent
+    // table reads of the next item travel while the current one is sorted
+    auto item_run = [&](int it, unsigned &len, unsigned &src) {
+        len = 0;
+        src = 0;
+        if (it >= nitems || tid >= S)
+            return;
+        const int g = it / G.n_units, b = it % G.n_units;
+        const int sl = g * S + tid;
+        if (sl < nslots) {
+            const int w = sl / kSubBatches, f = sl % kSubBatches;
+            if ((unsigned)f < sb_n[w]) {
+                const unsigned a = sb_start[(size_t)sl * kSubRow + b], e = sb_start[(size_t)sl * kSubRow + b + 1];
+                len = e - a;
+                src = sb_off[sl] + a;
+            }
+        }
+    };
+    unsigned len_next, src_next;
+    item_run(blockIdx.x, len_next, src_next);
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int g = it / G.n_units, b = it % G.n_units;  // (neighbouring items read neighbouring runs of the same sub-batches)
+        const unsigned len = len_next, src = src_next;
+        item_run(it + (int)gridDim.x, len_next, src_next);
+        lds_barrier();  // the previous item's tables and staging are no longer read
+        const unsigned off = block_exclusive_scan(len, s_wave);
+        if (tid < S) {
+            r_src[tid] = src;
+            r_off[tid] = off;
+        }
+        if (tid == S - 1)
+            r_off[S] = off + len;
+        for (int i = tid; i < ntc; i += kS2Block)
+            cnt[i] = 0;
+        lds_barrier();
+        const unsigned total = r_off[S];
+        unsigned *prow = ptab + ((size_t)b * (size_t)ngroups + (size_t)g) * (size_t)(ntc + 1);
+        // (an item whose runs do not add up to the total the project+bin kernel reported is dropped rather than
+        // written over its neighbours: cannot happen unless the two kernels disagree, and then the parity tests see it)
+        if (total == 0 || total != item_tot[it]) {  // (uniform)
+            for (int i = tid; i <= ntc; i += kS2Block)
+                prow[i] = 0;
+            continue;
+        }
+        const unsigned s_base = s_mybase[(it - (int)blockIdx.x) / (int)gridDim.x];
+        const bool multi = total > (unsigned)kS2Cap;
+        // windows of kS2Cap records of the concatenated runs; pass 0 of a multi-window item only counts (the item's
+        // tile starts must be known before its first record is placed)
+        for (int pass = multi ? 0 : 1; pass < 2; pass++) {
+            for (unsigned p0 = 0; p0 < total; p0 += kS2Cap) {
+                const unsigned p1 = p0 + kS2Cap < total ? p0 + kS2Cap : total, nsub = p1 - p0;
+                // run that holds the first record of every piece of 64 (binary search over the run starts)
+                for (unsigned pc = tid; pc < (nsub + 63) >> 6; pc += kS2Block) {
+                    const unsigned q = p0 + (pc << 6);
+                    int lo = 0, hi = S - 1;  // largest r with r_off[r] <= q
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (r_off[mid] <= q)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    first[pc] = (unsigned short)lo;
+                }
+                lds_barrier();
+                // gather: thread tid takes the window's records tid, tid + 512, ...: sixteen independent loads
+                float2 rec[kS2R];
+                unsigned sp[kS2R];
+#pragma unroll
+                for (int k = 0; k < kS2R; k++) {
+                    const unsigned i = (unsigned)k * kS2Block + tid;
+                    const unsigned q = p0 + (i < nsub ? i : nsub - 1);  // clamped: unconditional loads
+                    int r = first[(q - p0) >> 6];
+                    while (q >= r_off[r + 1])
+                        r++;
+#if defined(SLICER_S3X) && (SLICER_S3X & 1)  // timing experiment only
+                    rec[k] = make_float2(0.001f * (float)(q & 1023u), 0.0007f * (float)(q & 1023u));
+#else
+                    rec[k] = c1[r_src[r] + (q - r_off[r])];
+#endif
+                }
+#pragma unroll
+                for (int k = 0; k < kS2R; k++) {
+                    const unsigned i = (unsigned)k * kS2Block + tid;
+                    sp[k] = 0xFFFFFFFFu;
+                    if (i < nsub) {
+                        sp[k] = sort2_tile_of<POW2>(rec[k], P, G);
+                        atomicAdd(&cnt[sp[k]], 1u);
+                    }
+                }
+                lds_barrier();
+                const unsigned c = tid < ntc ? cnt[tid] : 0u;
+                if (pass == 0) {  // counting pass: leave the counts, the item's tile starts follow after the last window
+                    if (p1 < total)
+                        continue;
+                    const unsigned e = block_exclusive_scan(c, s_wave);
+                    if (tid < ntc) {
+                        cur[tid] = e;  // start of the tile's records inside the item
+                        prow[tid] = s_base + e;
+                        cnt[tid] = 0;
+                    }
+                    if (tid == 0)
+                        prow[ntc] = s_base + total;
+                    lds_barrier();
+                    continue;
+                }
+                const unsigned e = block_exclusive_scan(c, s_wave);
+                if (tid < ntc) {
+                    unsigned at;  // start of this window's records of the tile inside the item
+                    if (multi) {
+                        at = cur[tid];
+                    } else {
+                        at = e;
+                        prow[tid] = s_base + e;
+                    }
+                    pos[tid] = e;
+                    adj[tid] = s_base + at - e;
+                    cur[tid] = at + c;
+                    cnt[tid] = 0;
+                    if (c)
+                        atomicAdd(&tile_tot[(size_t)b * ntc + tid], c);
+                }
+                if (!multi && tid == 0)
+                    prow[ntc] = s_base + total;
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < kS2R; k++)
+                    if (sp[k] != 0xFFFFFFFFu) {
+                        const unsigned t = sp[k], at = atomicAdd(&pos[t], 1u);
+                        stage[at] = rec[k];
+                        scol[at] = (unsigned char)t;
+                    }
+                lds_barrier();
+#if !defined(SLICER_S3X) || !(SLICER_S3X & 2)
+                for (unsigned i = tid; i < nsub; i += kS2Block)
+                    sxy[adj[scol[i]] + i] = stage[i];
+#endif
+                if (p1 < total)
+                    lds_barrier();  // the next window overwrites the staging area
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: LDS-privatised tile deposit
 // ---------------------------------------------------------------------------------------------
 // Global accumulator type of each mode, and the type of the LDS tile cell.  Measured on MI355X
@@ -370,7 +586,7 @@ template <int ACC> constexpr bool kIntCells = ACC == kF32I || ACC == kF64I;
 // else must come out exact: T-TSC with k = 1) but added straight to the global map with a float atomic.  The kernel
 // tests one number per record -- the smallest of its nine products -- and notes the rare records that fail in an LDS
 // list, treated after the loop (slow_record); the loop itself stays branch-free.
-constexpr unsigned kSlowCap = 1024;  // noted records per work item (<= 16384 records: 1 % are ~160)
+constexpr unsigned kSlowCap = 512;  // noted records per work item (<= 16384 records: 1 % are ~160)
 
 // The quantum of an integer-cell tile: 2^(le - 49) with 2^le above the (largest) particle mass of the launch.  With one
 // constant mass it comes from the pass parameters; with per-particle masses from the largest selected mass the sort
@@ -461,8 +677,13 @@ __global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, T
     if (b >= nbins)
         return;
     unsigned tot = 0;
-    for (int c = 0; c < L.n; c++)
-        tot += L.base[c][b + 1] - L.base[c][b];
+    if (L.tot) {  // two-level sort: the sort kernel summed every pending chunk's records of the bin; zeroed for the next list
+        tot = L.tot[b];
+        L.tot[b] = 0;
+    } else {
+        for (int c = 0; c < L.n; c++)
+            tot += L.base[c][b + 1] - L.base[c][b];
+    }
     // (whole: the launch folds NGP counts file by file inside the tile kernel, which needs every tile in one workgroup)
     const unsigned np = (whole || tot <= kWholeRecs) ? (tot != 0) : (tot + kItemRecs - 1) / kItemRecs;
     I.nparts[b] = np;
@@ -475,7 +696,8 @@ __global__ __launch_bounds__(256) void k_build_items(PendingList L, int nbins, T
 
 constexpr int kTileBlock = 1024;
 
-// Deposit this work item's share of every pending chunk into the LDS tile.  CHECK = false for tiles whose halo
+// One-level sort (one run per pending chunk: L.base): deposit this work item's share of every pending chunk into the
+// LDS tile, the whole workgroup walking chunk by chunk.  CHECK = false for tiles whose halo
 // lies inside the map (all but the border tiles): the per-cell map-edge tests and their exec-mask bookkeeping go.
 struct NoBoundary {
     __device__ __forceinline__ void operator()(int, int) const {}
@@ -484,7 +706,7 @@ struct NoBoundary {
 // boundary(c, c_next) is called when the walk leaves chunk c for chunk c_next (c_end at the very end), after the
 // records of c_next's first round have been requested: the NGP path folds a finished sub-file there.
 template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK, typename Boundary = NoBoundary>
-__device__ __forceinline__ void tile_accumulate(const PendingList &L, const PassParams &P,
+__device__ __forceinline__ void tile_accumulate_chunks(const PendingList &L, const PassParams &P,
                                                 typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                 unsigned nparts, int x0, int y0, int W, unsigned *s_nslow,
                                                 uint2 *s_slow, typename AccT<ACC>::type *gmap, const TileQuantum &Q,
@@ -629,6 +851,250 @@ __device__ __forceinline__ void tile_accumulate(const PendingList &L, const Pass
     }
 }
 
+// The records of one work item: a table of runs in LDS.  A run is a contiguous range of one pending chunk's sorted
+// records: the chunk's whole (plane, tile) range with the one-level sort (k_bin_scatter: one run per chunk), or the
+// tile's range inside one item of the two-level sort (k_sort2: one run per chunk and group, ~100 records each).  A part
+// of a split bin takes the same fraction of every run.  The runs are walked as ONE sequence of records (s_pre: where
+// each run starts in it), 64 consecutive records per wave instruction whatever the run lengths are.
+struct RunRef {
+    unsigned chunk, start;  // records [start, start + length) of L.sxy[chunk]; length = s_pre[k + 1] - s_pre[k]
+};
+constexpr int kMaxRuns = kMaxPending * kMaxSortGroups;
+constexpr unsigned kWalkWindow = 65536;  // records walked per s_first table (kWalkWindow / 64 entries)
+
+struct RunTable {
+    RunRef *run;            // [kMaxRuns]
+    unsigned *pre;          // [kMaxRuns + 1] exclusive prefix of the run lengths
+    unsigned short *first;  // [kWalkWindow / 64] run that holds record 64 c of the current window
+    const float2 **sxy;     // [kMaxPending] sorted records of every pending chunk
+    float2 *mc;             // [kMaxPending] {mconst, sqrtf(mconst)} of every pending chunk
+    int n;
+};
+constexpr size_t kRunTableBytes = sizeof(RunRef) * kMaxRuns + 4 * (kMaxRuns + 1) + 4 + 2 * (kWalkWindow / 64) +
+                                  16 * kMaxPending;
+
+__device__ __forceinline__ RunTable run_table_at(unsigned char *p)  // p: 8-byte aligned
+{
+    RunTable R;
+    R.sxy = reinterpret_cast<const float2 **>(p);
+    R.mc = reinterpret_cast<float2 *>(p + 8 * kMaxPending);
+    R.run = reinterpret_cast<RunRef *>(p + 16 * kMaxPending);
+    R.pre = reinterpret_cast<unsigned *>(R.run + kMaxRuns);
+    R.first = reinterpret_cast<unsigned short *>(R.pre + kMaxRuns + 2);
+    R.n = 0;
+    return R;
+}
+
+// Fill the run table of (bin, part); every thread of the workgroup calls it (it holds barriers).
+__device__ __forceinline__ void build_run_table(const PendingList &L, const BinGeom &G, unsigned bin, unsigned part,
+                                                unsigned nparts, RunTable &R)
+{
+    const int tid = threadIdx.x;
+    const int n_runs = L.run0[L.n];
+    R.n = n_runs;
+    if (tid < L.n) {
+        R.sxy[tid] = L.sxy[tid];
+        R.mc[tid] = make_float2(L.mconst[tid], L.sm_const[tid]);
+    }
+    for (int k = tid; k < n_runs; k += kTileBlock) {
+        int c = 0;
+        while (c + 1 < L.n && k >= L.run0[c + 1])
+            c++;
+        unsigned a, e;
+        if (L.ptab[c]) {  // two-level sort: item (unit, group) of chunk c, entry tile-in-unit
+            const unsigned unit = bin / (unsigned)G.tiles_per_unit, t = bin % (unsigned)G.tiles_per_unit;
+            const unsigned g = (unsigned)(k - L.run0[c]);
+            const unsigned *tab = L.ptab[c] + ((size_t)unit * (size_t)L.ngroups[c] + g) * (size_t)(G.tiles_per_unit + 1);
+            a = tab[t];
+            e = tab[t + 1];
+        } else {
+            a = L.base[c][bin];
+            e = L.base[c][bin + 1];
+        }
+        const unsigned len = e - a;
+        const unsigned lo = (unsigned)(((unsigned long long)len * part) / nparts);
+        const unsigned hi = (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
+        RunRef r;
+        r.chunk = (unsigned)c;
+        r.start = a + lo;
+        R.run[k] = r;
+        R.pre[k + 1] = hi - lo;  // (lengths first; the prefix follows)
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive prefix over <= 256 lengths: four per lane of wave 0
+        constexpr int PER = kMaxRuns / 64;
+        unsigned v[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int k = tid * PER + j;
+            v[j] = k < n_runs ? R.pre[k + 1] : 0u;
+            sum += v[j];
+        }
+        unsigned x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = (unsigned)__shfl_up((int)x, d);
+            if (tid >= d)
+                x += y;
+        }
+        unsigned e = x - sum;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int k = tid * PER + j;
+            e += v[j];
+            if (k < n_runs)
+                R.pre[k + 1] = e;
+        }
+        if (tid == 0)
+            R.pre[0] = 0;
+    }
+    __syncthreads();
+}
+
+// Deposit the runs [k_begin, k_end) of the table into the LDS tile.  Every thread of the workgroup calls it (barriers
+// around the s_first table); inside, every WAVE walks on its own: the records of the runs form one sequence, cut into
+// pieces of 64; wave w takes pieces w, w + 16, ... -- two in flight, the next two requested before the current ones are
+// deposited.  A lane finds its record's run from the piece's first run (s_first) and the run boundaries that follow.
+// CHECK = false for tiles whose halo lies inside the map (all but the border tiles): the per-cell map-edge tests and
+// their exec-mask bookkeeping go.
+template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool CHECK>
+__device__ __forceinline__ void tile_accumulate(const PassParams &P, typename AccT<ACC>::lds *tile, const RunTable &R,
+                                                int k_begin, int k_end, int x0, int y0, int W, unsigned *s_nslow,
+                                                uint2 *s_slow, typename AccT<ACC>::type *gmap, const TileQuantum &Q)
+{
+    using lds_t = typename AccT<ACC>::lds;
+    const unsigned lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    constexpr int NW = kTileBlock / 64;
+    const int nn = P.nn;
+#ifndef SLICER_K4_UR
+#define SLICER_K4_UR 2
+#endif
+    constexpr int U = SLICER_K4_UR;  // pieces (of 64 records) in flight per wave
+    const unsigned q_begin = R.pre[k_begin], q_end = R.pre[k_end];
+    for (unsigned w0 = q_begin; w0 < q_end; w0 += kWalkWindow) {  // (one window unless a tile holds > 65536 records)
+        const unsigned w1 = q_end - w0 > kWalkWindow ? w0 + kWalkWindow : q_end;
+        const unsigned npiece = (w1 - w0 + 63) >> 6;
+        if (w0 != q_begin)
+            __syncthreads();  // the previous window's table is no longer read
+        for (unsigned pc = threadIdx.x; pc < npiece; pc += kTileBlock) {  // run that holds the piece's first record
+            const unsigned q = w0 + (pc << 6);
+            int lo = k_begin, hi = k_end - 1;  // largest k with pre[k] <= q
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (R.pre[mid] <= q)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            R.first[pc] = (unsigned short)lo;
+        }
+        __syncthreads();
+        struct Rec {
+            float2 r;
+            float m;
+            unsigned i, c;  // record index inside its chunk, chunk (c = ~0: no record)
+        };
+        auto fetch = [&](unsigned pc, Rec &o) {
+            o.c = 0xFFFFFFFFu;
+            o.i = 0;
+            o.r = make_float2(0.f, 0.f);
+            o.m = 0.f;
+            if (pc >= npiece)
+                return;
+            const unsigned q = w0 + (pc << 6) + lane;
+            const unsigned qc = q < w1 ? q : w1 - 1;  // clamped: an unconditional load (a load under a lane-dependent
+                                                        // branch makes the compiler drain the memory queue first)
+            int k = R.first[pc];
+            while (qc >= R.pre[k + 1])
+                k++;
+            const RunRef rr = R.run[k];
+            const unsigned i = rr.start + (qc - R.pre[k]);
+            const float2 *__restrict__ sxy = R.sxy[rr.chunk];
+            if (HAS_MASS) {
+                const Rec3 v = reinterpret_cast<const Rec3 *>(sxy)[i];
+                o.r = make_float2(v.x, v.y);
+                o.m = v.m;
+            } else {
+                o.r = sxy[i];
+            }
+            o.i = i;
+            o.c = q < w1 ? rr.chunk : 0xFFFFFFFFu;
+        };
+        Rec cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            fetch((unsigned)wave + (unsigned)(u * NW), cur[u]);
+        for (unsigned pc = (unsigned)wave; pc < npiece; pc += U * NW) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                fetch(pc + (unsigned)((U + u) * NW), nxt[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned c = cur[u].c, i = cur[u].i;
+                if (c == 0xFFFFFFFFu)
+                    continue;
+                const float xs = cur[u].r.x, ys = cur[u].r.y;
+                const float2 mc = R.mc[c];
+                float m = mc.x, sq = mc.y;
+                if (HAS_MASS) {
+                    m = cap_mass(cur[u].m);
+                    sq = __fsqrt_rn(m);
+                }
+                const int gx = grid_index<POW2>(xs, P);
+                const int gy = grid_index<POW2>(ys, P);
+                if (MAS == kNGP) {
+                    lds_t *cell = tile + (gy - y0 + 1) * W + (gx - x0 + 1);
+                    if (ACC == kCountU32)
+                        atomicAdd(reinterpret_cast<unsigned *>(cell), 1u);
+                    else
+                        atomicAdd(reinterpret_cast<double *>(cell), (double)m);
+                } else {
+                    float wx[3], wy[3];
+                    tsc_axis<POW2>(xs, gx, P, wx);
+                    tsc_axis<POW2>(ys, gy, P, wy);
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        wx[a] = sq * wx[a];
+                        wy[a] = sq * wy[a];
+                    }
+                    if (kIntCells<ACC>) {
+                        // smallest of the nine products (weights are >= 0; the centre cell holds the largest)
+                        if (HAS_MASS && m == 0.0f)
+                            continue;  // (a mass above MAX_M counts as 0: nine additions of +0)
+                        const float cmin = fminf(wx[0], wx[2]) * fminf(wy[0], wy[2]);
+                        if (cmin < Q.cmin) {  // rare: a contribution that is not a multiple of the tile's quantum
+                            const unsigned kq = atomicAdd(s_nslow, 1u);
+                            if (kq < kSlowCap)
+                                s_slow[kq] = make_uint2(c, i);
+                            else
+                                slow_record<ACC, POW2>(xs, ys, sq, P, Q, tile, gmap, x0, y0, W);
+                            continue;
+                        }
+                    }
+                    lds_t *cell0 = tile + (gy - y0) * W + (gx - x0);  // cell (gx - 1, gy - 1)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        const int py = gy + b - 1;
+                        if (CHECK && (py < 0 || py >= nn))
+                            continue;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const int px = gx + a - 1;
+                            if (CHECK && (px < 0 || px >= nn))
+                                continue;
+                            lds_add<ACC>(cell0 + b * W + a, wx[a] * wy[b], P, Q);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                cur[u] = nxt[u];
+        }
+    }
+}
+
 // the k-fold sequential f32 sum s <- fl(s + m) of utilities.cpp:75: what a pixel of the reference's per-file NGP map holds
 __device__ __forceinline__ float ngp_seq_sum(unsigned k, float m)
 {
@@ -660,7 +1126,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 }
 
 template <int MAS, int ACC, bool POW2, bool HAS_MASS>
-__device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, const PassParams &P,
+__device__ __forceinline__ void tile_accumulate_merged_chunks(const PendingList &L, const PassParams &P,
                                                        typename AccT<ACC>::lds *tile, unsigned bin, unsigned part,
                                                        unsigned nparts, int x0, int y0, int W,
                                                        typename AccT<ACC>::type *gmap, const TileQuantum &Q)
@@ -674,6 +1140,111 @@ __device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, con
         const unsigned end = run0 + (unsigned)(((unsigned long long)len * (part + 1)) / nparts);
         const float2 *__restrict__ sxy = L.sxy[c];
         // every lane of the workgroup runs every iteration (no divergent exit: the butterfly needs all lanes)
+        for (unsigned i0 = start; i0 < end; i0 += kTileBlock) {
+            const unsigned i = i0 + tid;
+            const bool act = i < end;
+            float2 r = make_float2(0.f, 0.f);
+            float m = L.mconst[c], sq = L.sm_const[c];
+            if (HAS_MASS) {
+                Rec3 v{0.f, 0.f, 0.f};
+                if (act)
+                    v = reinterpret_cast<const Rec3 *>(sxy)[i];
+                r = make_float2(v.x, v.y);
+                m = cap_mass(v.m);
+                sq = __fsqrt_rn(m);
+            } else if (act) {
+                r = sxy[i];
+            }
+            const int gx = grid_index<POW2>(r.x, P), gy = grid_index<POW2>(r.y, P);
+            const int cell = act ? (gy - y0) * W + (gx - x0) : -1;  // cell (gx - 1, gy - 1) of the halo'd tile
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull)
+                continue;
+            const int lead = (int)__builtin_ctzll(am);
+            const int cell0 = __shfl(cell, lead);
+            const bool uniform = __ballot(act && cell != cell0) == 0ull;
+            if (MAS == kNGP) {
+                if (uniform) {
+                    if ((int)lane_id() == lead) {
+                        lds_t *cc = tile + cell0 + W + 1;
+                        if (ACC == kCountU32)
+                            atomicAdd(reinterpret_cast<unsigned *>(cc), (unsigned)__popcll(am));
+                    }
+                    if (ACC != kCountU32) {
+                        const double tot = wave_sum(act ? (double)m : 0.0);
+                        if ((int)lane_id() == lead)
+                            atomicAdd(reinterpret_cast<double *>(tile + cell0 + W + 1), tot);
+                    }
+                } else if (act) {
+                    lds_t *cc = tile + cell + W + 1;
+                    if (ACC == kCountU32)
+                        atomicAdd(reinterpret_cast<unsigned *>(cc), 1u);
+                    else
+                        atomicAdd(reinterpret_cast<double *>(cc), (double)m);
+                }
+                continue;
+            }
+            float wx[3], wy[3];
+            tsc_axis<POW2>(r.x, gx, P, wx);
+            tsc_axis<POW2>(r.y, gy, P, wy);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                wx[a] = sq * wx[a];
+                wy[a] = sq * wy[a];
+            }
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    // map-edge tests as in the CHECK variant (heavy border tiles are rare enough not to specialise)
+                    const int px = gx + a - 1, py = gy + b - 1;
+                    bool in = act && px >= 0 && px < nn && py >= 0 && py < nn;
+                    const float cf = wx[a] * wy[b];
+                    if (kIntCells<ACC>) {  // contributions that are no multiple of the tile's quantum bypass the tile
+                        const double t = (double)cf * Q.scale;
+                        if (in && t != rint(t)) {
+                            atomicAdd(gmap + (size_t)px + (size_t)nn * (size_t)py, (typename AccT<ACC>::type)cf);
+                            in = false;
+                        }
+                    }
+                    if (uniform) {  // wave-uniform branch
+                        if (kIntCells<ACC>) {
+                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, Q.scale) : 0ull);
+                            if ((int)lane_id() == lead && tot)
+                                atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
+                        } else if (ACC == kFixed64) {
+                            const unsigned long long tot = wave_sum(in ? rn_scaled_u64(cf, P.fixed_scale) : 0ull);
+                            if ((int)lane_id() == lead && tot)
+                                atomicAdd(reinterpret_cast<unsigned long long *>(tile + cell0 + b * W + a), tot);
+                        } else {
+                            const double tot = wave_sum(in ? (double)cf : 0.0);
+                            if ((int)lane_id() == lead && tot != 0.0)
+                                atomicAdd(reinterpret_cast<double *>(tile + cell0 + b * W + a), tot);
+                        }
+                    } else if (in) {
+                        lds_add<ACC>(tile + cell + b * W + a, cf, P, Q);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+__device__ __forceinline__ void tile_accumulate_merged(const PendingList &L, const PassParams &P,
+                                                       typename AccT<ACC>::lds *tile, const RunTable &R, int x0, int y0,
+                                                       int W, typename AccT<ACC>::type *gmap, const TileQuantum &Q)
+{
+    using lds_t = typename AccT<ACC>::lds;
+    const int tid = threadIdx.x;
+    const int nn = P.nn;
+    for (int kk = 0; kk < R.n; kk++) {
+        const RunRef rr = R.run[kk];
+        const int c = __builtin_amdgcn_readfirstlane((int)rr.chunk);
+        const unsigned start = (unsigned)__builtin_amdgcn_readfirstlane((int)rr.start);
+        const unsigned end = start + (unsigned)__builtin_amdgcn_readfirstlane((int)(R.pre[kk + 1] - R.pre[kk]));
+        const float2 *__restrict__ sxy = L.sxy[c];
+        // every lane of a wave runs every iteration of its wave (no divergent exit: the butterfly needs all lanes)
         for (unsigned i0 = start; i0 < end; i0 += kTileBlock) {
             const unsigned i = i0 + tid;
             const bool act = i < end;
@@ -778,7 +1349,9 @@ __device__ __forceinline__ void for_each_tile_cell(int W, int H, Fn &&fn)
         fn(i >> 1, W - 2 + (i & 1));
 }
 
-template <int MAS, int ACC, bool POW2, bool HAS_MASS>
+// RUNS: the pending chunks come from the two-level sort (a table of runs per tile, walked wave by wave); otherwise one
+// run per chunk (L.base), walked by the whole workgroup.
+template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool RUNS>
 __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
                                                              TileItems I, NgpFold F)
 {
@@ -815,8 +1388,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
 
     // behind the tile (no static __shared__ in this kernel: it would sit in front of the dynamic array and leave the
     // 8-byte cells 4-byte aligned -- misaligned 64-bit LDS atomics fault): a counter, then the list of noted records
-    unsigned &s_nslow = *reinterpret_cast<unsigned *>(tile + cells);
-    uint2 *s_slow = reinterpret_cast<uint2 *>(tile + cells) + 1;  // [kSlowCap] {chunk, record}: integer-cell modes only
+    unsigned char *behind = smem_raw + ((sizeof(lds_t) * (size_t)cells + 7) & ~(size_t)7);
+    unsigned &s_nslow = *reinterpret_cast<unsigned *>(behind);
+    uint2 *s_slow = reinterpret_cast<uint2 *>(behind) + 1;  // [kSlowCap] {chunk, record}: integer-cell modes only
+    RunTable R = run_table_at(behind + 8 + (kIntCells<ACC> ? kSlowCap * sizeof(uint2) : 0));
     acc_t *gmap = reinterpret_cast<acc_t *>(T.acc[plane]);
     TileQuantum Q{P.tile_scale, P.tile_inv_scale, P.tile_cmin};
     if (kIntCells<ACC> && HAS_MASS) {
@@ -831,7 +1406,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
         tile[i] = (lds_t)0;
     if (tid == 0)
         s_nslow = 0;
-    __syncthreads();
+    if (RUNS)
+        build_run_table(L, G, bin, part, nparts, R);  // (ends in a barrier: tile zeroed, table complete)
+    else
+        __syncthreads();
 
     // the halo [x0 - 1, x0 + W - 2] x [y0 - 1, y0 + H - 2] inside the map: no cell of this tile needs the edge test
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + W - 2 < nn && y0 + H - 2 < nn;
@@ -867,11 +1445,9 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
             }
         }
         unsigned touched = 0;
-        // one walk over all pending chunks; when it leaves the last chunk of a sub-file (the next round's records are
-        // already on their way) the file's counts are folded, or flushed to the count map
-        auto boundary = [&](int c, int c_next) {
-            if (c_next < L.n && L.file_id[c_next] == L.file_id[c])
-                return;
+        // one sub-file after the other: the runs of its chunks are deposited (every wave walks its share), then the
+        // file's counts are folded, or flushed to the count map
+        auto boundary = [&](int c) {
             __syncthreads();
             if (F.on && L.fold[c]) {
                 const float m = L.mconst[c];
@@ -902,8 +1478,27 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
             }
             __syncthreads();
         };
-        tile_accumulate<MAS, ACC, POW2, false, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap, Q, 0,
-                                                      L.n, boundary);
+        if (RUNS) {
+            for (int c0 = 0; c0 < L.n;) {
+                int c1 = c0 + 1;
+                while (c1 < L.n && L.file_id[c1] == L.file_id[c0])
+                    c1++;
+                tile_accumulate<MAS, ACC, POW2, false, false>(P, tile, R, L.run0[c0], L.run0[c1], x0, y0, W, &s_nslow,
+                                                              s_slow, gmap, Q);
+                boundary(c0);
+                c0 = c1;
+            }
+        } else {
+            // one walk over all pending chunks; when it leaves the last chunk of a sub-file (the next round's records
+            // are already on their way) the file's counts are folded, or flushed to the count map
+            auto leave = [&](int c, int c_next) {
+                if (c_next < L.n && L.file_id[c_next] == L.file_id[c])
+                    return;
+                boundary(c);
+            };
+            tile_accumulate_chunks<MAS, ACC, POW2, false, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow,
+                                                                 gmap, Q, 0, L.n, leave);
+        }
 #pragma unroll
         for (int j = 0; j < CPT; j++)
             if (touched >> j & 1u) {
@@ -915,14 +1510,23 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, Pass
     }
     // pre-reduction only for bins far beyond a tile's usual load (>= 8 parts = 131072 records: a halo core); a bin that
     // is merely split in two or three is faster through the plain loop (--clustered: 810 us with, 700 us without)
-    if (nparts >= kMergeParts)
-        tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap, Q);
-    else if (MAS == kNGP || interior)
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
-                                                         Q, 0, L.n);
-    else
-        tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow, s_slow, gmap,
-                                                        Q, 0, L.n);
+    if (RUNS) {
+        if (nparts >= kMergeParts)
+            tile_accumulate_merged<MAS, ACC, POW2, HAS_MASS>(L, P, tile, R, x0, y0, W, gmap, Q);
+        else if (MAS == kNGP || interior)
+            tile_accumulate<MAS, ACC, POW2, HAS_MASS, false>(P, tile, R, 0, R.n, x0, y0, W, &s_nslow, s_slow, gmap, Q);
+        else
+            tile_accumulate<MAS, ACC, POW2, HAS_MASS, true>(P, tile, R, 0, R.n, x0, y0, W, &s_nslow, s_slow, gmap, Q);
+    } else {
+        if (nparts >= kMergeParts)
+            tile_accumulate_merged_chunks<MAS, ACC, POW2, HAS_MASS>(L, P, tile, bin, part, nparts, x0, y0, W, gmap, Q);
+        else if (MAS == kNGP || interior)
+            tile_accumulate_chunks<MAS, ACC, POW2, HAS_MASS, false>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow,
+                                                                    s_slow, gmap, Q, 0, L.n);
+        else
+            tile_accumulate_chunks<MAS, ACC, POW2, HAS_MASS, true>(L, P, tile, bin, part, nparts, x0, y0, W, &s_nslow,
+                                                                   s_slow, gmap, Q, 0, L.n);
+    }
     __syncthreads();
     if (kIntCells<ACC>) {
         // the records noted in the loop: those of their contributions that are exact multiples of the quantum go into
@@ -1005,11 +1609,41 @@ hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, i
     return hipGetLastError();
 }
 
+size_t sort2_lds_bytes(int slots_per_group, int tiles_per_unit)
+{
+    return (size_t)kS2Cap * 9 + 4 * ((size_t)slots_per_group * 2 + 1 + 4 * (size_t)tiles_per_unit) + 2 * (kS2Cap / 64);
+}
+
+hipError_t launch_sort2(int nblocks, int slots_per_group, int ngroups, int max_workgroups, const PassParams &P,
+                        const BinGeom &G, const BinWorkspace &W, hipStream_t s)
+{
+    const size_t lds = sort2_lds_bytes(slots_per_group, G.tiles_per_unit);
+    const int nitems = G.n_units * ngroups;
+    const int nwg = std::min(nitems, std::max(std::max(8, max_workgroups), (nitems + kS2MaxMine - 1) / kS2MaxMine));
+    hipError_t e;
+#define S2(P2_)                                                                                                       \
+    do {                                                                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort2<P2_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                            \
+        if (e != hipSuccess)                                                                                          \
+            return e;                                                                                                 \
+        k_sort2<P2_><<<nwg, kS2Block, lds, s>>>(W.c1, W.sb_off, W.sb_start, W.sb_n, nblocks, slots_per_group, ngroups, G, P, \
+                                                W.sxy, W.ptab, W.item_tot, W.tot);                                      \
+    } while (0)
+    if (P.pow2)
+        S2(true);
+    else
+        S2(false);
+#undef S2
+    return hipGetLastError();
+}
+
 size_t tile_lds_bytes(const BinGeom &G, int acc)
 {
     const size_t elem = acc == kCountU32 ? 4 : 8;
     const size_t cells = (size_t)((1 << G.tw_log2) + 2) * (size_t)((1 << G.th_log2) + 2);
-    return ((elem * cells + 7) & ~(size_t)7) + 8 + ((acc == kF32I || acc == kF64I) ? kSlowCap * sizeof(uint2) : 0);
+    return ((elem * cells + 7) & ~(size_t)7) + 8 + ((acc == kF32I || acc == kF64I) ? kSlowCap * sizeof(uint2) : 0) +
+           kRunTableBytes;
 }
 
 template <int MAS, int ACC>
@@ -1017,9 +1651,9 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
                             const Targets &T, const TileItems &I, const NgpFold &F, unsigned max_items, hipStream_t s)
 {
     const size_t lds = tile_lds_bytes(G, ACC);
-#define K4(P2_, HM_)                                                                                             \
+#define K4_(P2_, HM_, RN_)                                                                                       \
     do {                                                                                                         \
-        auto kern = k_tile_deposit<MAS, ACC, P2_, HM_>;                                                          \
+        auto kern = k_tile_deposit<MAS, ACC, P2_, HM_, RN_>;                                                     \
         if (lds > 48 * 1024) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
@@ -1028,12 +1662,20 @@ static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const
         }                                                                                                        \
         kern<<<max_items, kTileBlock, lds, s>>>(L, P, G, T, I, F);                                      \
     } while (0)
+#define K4(P2_, HM_)                                                                                             \
+    do {                                                                                                         \
+        if (L.tot)                                                                                               \
+            K4_(P2_, HM_, true);                                                                                 \
+        else                                                                                                     \
+            K4_(P2_, HM_, false);                                                                                \
+    } while (0)
     if (pow2) {
         if (has_mass) K4(true, true); else K4(true, false);
     } else {
         if (has_mass) K4(false, true); else K4(false, false);
     }
 #undef K4
+#undef K4_
     return hipGetLastError();
 }
 

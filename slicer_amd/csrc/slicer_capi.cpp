@@ -36,9 +36,9 @@ struct ProfEntry {
     hipEvent_t e0, e1;
 };
 
-const char *kKernelNames[] = {"direct_deposit", "finalize_tsc", "fold_ngp",  "synth",
-                              "project_bin",    "bin_scan",     "bin_scatter", "tile_deposit", "debug_project"};
-enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SCATTER, KN_TILE, KN_DEBUG, KN_COUNT };
+const char *kKernelNames[] = {"direct_deposit", "finalize_tsc", "fold_ngp",  "synth",         "project_bin",
+                              "bin_scan",       "bin_scatter",  "tile_deposit", "debug_project", "bin_sort"};
+enum { KN_DIRECT = 0, KN_FINALIZE, KN_FOLD, KN_SYNTH, KN_PROJECT, KN_SCAN, KN_SCATTER, KN_TILE, KN_DEBUG, KN_SORT2, KN_COUNT };
 
 }  // namespace
 
@@ -56,6 +56,8 @@ struct Options {
     int k1_stack = -1;    // fast project+bin kernel: compact survivors through the wave stack (0 / 1; -1 = by slab depth)
     int ngp_general = 0;  // 1: no in-tile NGP fold (count map + k_fold_ngp)
     int dl_quot = 1;      // maps that are not a power of two wide: allow the swept reciprocal-product quotient
+    int sort2 = 0;        // 1: two-level sort (project+bin sorts by coarse bin in LDS, k_sort2 by tile) where a pass
+                          // qualifies.  Off by default: it moves fewer bytes but costs more instructions
 };
 struct OptionName {
     const char *key, *env;
@@ -72,6 +74,7 @@ const OptionName kOptionNames[] = {
     {"k1_stack", "SLICER_K1_STACK", &Options::k1_stack},
     {"ngp_general", "SLICER_NGP_GENERAL", &Options::ngp_general},
     {"dl_quot", "SLICER_DL_QUOT", &Options::dl_quot},
+    {"sort2", "SLICER_SORT2", &Options::sort2},
 };
 
 struct slicer_handle_s {
@@ -118,6 +121,7 @@ struct slicer_handle_s {
 
     // SLICER_ALGO_BINNED workspace (sized for max_chunk particles)
     DevBuf w_cxy, w_cbin, w_cm, w_hist, w_hist16, w_total, w_bcount, w_items;
+    DevBuf w_c1, w_sboff, w_sbstart, w_sbn;  // two-level sort: project+bin output of the current chunk
     // box sizes whose f32 quotient r/box passed (true) or failed (false) the exhaustive device sweep
     // (launch_check_box_quotient): k_project_bin_fast is only used for the former
     std::vector<std::pair<double, bool>> box_verdicts;
@@ -152,6 +156,9 @@ struct slicer_handle_s {
         Targets T{};
         uint64_t particles = 0;  // particles behind the pending chunks (bounds their record count)
         DevBuf w_sxy[kMaxPending], w_base[kMaxPending];  // one sorted slot per pending chunk
+        // two-level sort: the chunk's item table (w_base then holds the items' allocation cursor), the group's bin totals
+        DevBuf w_ptab[kMaxPending], w_tot;
+        bool sort2 = false;
     };
     Pending pg[SLICER_MAX_PLANES];
 
@@ -712,6 +719,54 @@ int ensure_bin_workspace(slicer_handle h, bool has_mass, int group, int slot, ui
     return SLICER_OK;
 }
 
+// Two-level sort: the units of the pass become coarse bins -- bands of 2^crow_log2 tile rows of one plane -- chosen so
+// that a pass has about 64 of them (runs of ~0.5 KB in the project+bin kernel's sub-batches as well as in the sort
+// kernel's items) within the 8-bit ids of both kernels.  False if the pass does not fit (the one-level sort serves it).
+bool sort2_geom(const BinGeom &G, int n_planes, BinGeom &G2, int &crow_log2)
+{
+    G2 = G;
+    crow_log2 = 0;
+    auto units = [&](int cl) { return n_planes * ((G.nty + (1 << cl) - 1) >> cl); };
+    while (units(crow_log2) > 64 && (2 << crow_log2) * G.ntx <= kMaxCoarseTiles)
+        crow_log2++;
+    G2.rows_per_unit = 1 << crow_log2;
+    G2.units_per_plane = (G.nty + G2.rows_per_unit - 1) / G2.rows_per_unit;
+    G2.tiles_per_unit = G2.rows_per_unit * G.ntx;
+    G2.n_units = n_planes * G2.units_per_plane;
+    G2.nbins = G2.n_units * G2.tiles_per_unit;
+    return G2.n_units <= kMaxCoarse && G2.tiles_per_unit <= kMaxCoarseTiles && G.region == G.batch && G.batch <= 32768;
+}
+
+constexpr int kSort2Slots = kSort2Blocks * kSubBatches;  // sub-batch slots per item of the sort kernel
+
+int ensure_sort2_workspace(slicer_handle h, int group, int slot, uint64_t n, const BinGeom &G, int ngroups, BinWorkspace &W)
+{
+    auto &Q = h->pg[group];
+    const uint64_t nb = (n + G.batch - 1) / G.batch, nslots = nb * kSubBatches;
+    int rc;
+    bool fresh_tot = false;
+    if ((rc = ensure(h, h->w_c1, nb * (uint64_t)G.batch * 8)) || (rc = ensure(h, h->w_sboff, nslots * 4)) ||
+        (rc = ensure(h, h->w_sbstart, (uint64_t)kSubRow * nslots * 2)) || (rc = ensure(h, h->w_sbn, nb * 4)) ||
+        (rc = ensure(h, Q.w_sxy[slot], n * 8)) || (rc = ensure(h, Q.w_base[slot], (kMaxBins + 1) * 4)) ||
+        (rc = ensure(h, Q.w_ptab[slot], (uint64_t)G.n_units * ngroups * (G.tiles_per_unit + 1) * 4)) ||
+        (rc = ensure(h, Q.w_tot, (uint64_t)kMaxCoarse * kMaxCoarseTiles * 4, &fresh_tot)))
+        return rc;
+    memset(&W, 0, sizeof W);
+    W.c1 = (float2 *)h->w_c1.p;
+    W.sb_off = (unsigned *)h->w_sboff.p;
+    W.sb_start = (unsigned short *)h->w_sbstart.p;
+    W.sb_n = (unsigned *)h->w_sbn.p;
+    W.sxy = (float2 *)Q.w_sxy[slot].p;
+    W.ptab = (unsigned *)Q.w_ptab[slot].p;
+    W.item_tot = (unsigned *)Q.w_base[slot].p;
+    W.tot = (unsigned *)Q.w_tot.p;
+    W.base = (unsigned *)Q.w_base[slot].p;
+    if (slot == 0 || fresh_tot)  // a new pending list starts from zero totals (the tile launch's item builder re-zeroes them)
+        HIPCHK(h, hipMemsetAsync(W.tot, 0, (size_t)G.nbins * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(W.item_tot, 0, (size_t)ngroups * G.n_units * 4, h->stream));
+    return SLICER_OK;
+}
+
 bool ngp_foldable(slicer_handle h, int type)
 {
     int species = 0;
@@ -762,6 +817,10 @@ int flush_group(slicer_handle h, int group)
         HIPCHK(h, hipMemsetAsync(h->w_items.p, 0, 16, h->stream));
         h->items_epoch = 0;
     }
+    Q.L.run0[0] = 0;
+    for (int c = 0; c < Q.L.n; c++)
+        Q.L.run0[c + 1] = Q.L.run0[c] + (Q.L.ptab[c] ? Q.L.ngroups[c] : 1);
+    Q.L.tot = Q.sort2 ? (unsigned *)Q.w_tot.p : nullptr;
     {
         ProfScope ps(h, KN_TILE);
         bool int_cells = false;
@@ -925,32 +984,64 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
     const bool shared = d.mas != SLICER_MAS_NGP && !d.want_type_maps;
     const int key = (shared ? 12 : type * 2) + (has_mass ? 1 : 0);
     int rc;
-    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending) && (rc = flush_group(h, group)))
-        return rc;
-    const int slot = Q.L.n;
-    BinWorkspace W;
-    if ((rc = ensure_bin_workspace(h, has_mass, group, slot, n, G, W)))
-        return rc;
-    const int nblocks = (int)((n + G.batch - 1) / G.batch);
+    int nblocks = (int)((n + G.batch - 1) / G.batch);
     K1Args A;
     bool fast = false;
     if ((rc = k1_fast_args(h, P, G, nblocks, A, fast)))
         return rc;
+    // two-level sort where the pass qualifies: the fast project+bin kernel without the wave stacks, constant mass, a unit
+    // table within the 8-bit ids, at most kMaxSortGroups items per unit
+    BinGeom G2;
+    int crow_log2 = 0;
+    const bool sort2 = fast && h->opt.sort2 && !has_mass && !A.stack && sort2_geom(G, P.n_planes, G2, crow_log2) &&
+                       (nblocks * kSubBatches + kSort2Slots - 1) / kSort2Slots <= kMaxSortGroups;
+    if (sort2) {
+        G = G2;
+        A.sort2 = 1;
+        A.crow_log2 = crow_log2;
+    }
+    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending || Q.sort2 != sort2) &&
+        (rc = flush_group(h, group)))
+        return rc;
+    const int slot = Q.L.n;
+    BinWorkspace W;
     h->algo_mask |= fast ? (1 << 4) : (1 << 5);
-    {
-        ProfScope ps(h, KN_PROJECT);
-        HIPCHK(h, launch_project_bin(cfg, fast, d_pos, d_mass, n, P, A, G, W, T, h->stream));
-    }
-    {
-        ProfScope ps(h, KN_SCAN);
-        HIPCHK(h, launch_bin_scan(cfg, nblocks, P.n_planes, G, W, T, h->stream));
-    }
-    {
-        ProfScope ps(h, KN_SCATTER);
-        HIPCHK(h, launch_bin_scatter(cfg, nblocks, P.n_planes, scatter_workgroups(h), G, W, T, h->stream));
+    if (sort2) {
+        const int ngroups = (nblocks * kSubBatches + kSort2Slots - 1) / kSort2Slots;
+        if ((rc = ensure_sort2_workspace(h, group, slot, n, G, ngroups, W)))
+            return rc;
+        h->algo_mask |= 1 << 7;
+        {
+            ProfScope ps(h, KN_PROJECT);
+            HIPCHK(h, launch_project_bin(cfg, true, d_pos, d_mass, n, P, A, G, W, T, h->stream));
+        }
+        {
+            ProfScope ps(h, KN_SORT2);
+            HIPCHK(h, launch_sort2(nblocks, kSort2Slots, ngroups, scatter_workgroups(h), P, G, W, h->stream));
+        }
+        Q.L.ptab[slot] = W.ptab;
+        Q.L.ngroups[slot] = ngroups;
+    } else {
+        if ((rc = ensure_bin_workspace(h, has_mass, group, slot, n, G, W)))
+            return rc;
+        {
+            ProfScope ps(h, KN_PROJECT);
+            HIPCHK(h, launch_project_bin(cfg, fast, d_pos, d_mass, n, P, A, G, W, T, h->stream));
+        }
+        {
+            ProfScope ps(h, KN_SCAN);
+            HIPCHK(h, launch_bin_scan(cfg, nblocks, P.n_planes, G, W, T, h->stream));
+        }
+        {
+            ProfScope ps(h, KN_SCATTER);
+            HIPCHK(h, launch_bin_scatter(cfg, nblocks, P.n_planes, scatter_workgroups(h), G, W, T, h->stream));
+        }
+        Q.L.ptab[slot] = nullptr;
+        Q.L.ngroups[slot] = 1;
     }
     if (slot == 0) {
         Q.key = key;
+        Q.sort2 = sort2;
         Q.p0 = p0;
         Q.np = np;
         Q.cfg = cfg;
@@ -1216,13 +1307,16 @@ int slicer_destroy(slicer_handle h)
     if (h->d_sweep)
         (void)hipFree(h->d_sweep);
     for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
-                      &h->w_tcounts, &h->w_tbase, &h->w_urand})
+                      &h->w_tcounts, &h->w_tbase, &h->w_urand, &h->w_c1, &h->w_sboff, &h->w_sbstart, &h->w_sbn})
         release(*b);
-    for (auto &Q : h->pg)
+    for (auto &Q : h->pg) {
+        release(Q.w_tot);
         for (int i = 0; i < kMaxPending; i++) {
             release(Q.w_sxy[i]);
             release(Q.w_base[i]);
+            release(Q.w_ptab[i]);
         }
+    }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->d_stage[i]) (void)hipFree(h->d_stage[i]);

@@ -88,6 +88,13 @@ constexpr int kMaxUnits = 32;
 constexpr int kMaxBins = 32768;  // all (unit, tile) bins of a pass: K1's packed u16 histogram is <= 64 KiB of LDS
 
 struct BinWorkspace {
+    // two-level sort
+    float2 *c1;
+    unsigned *sb_off, *sb_n;
+    unsigned short *sb_start;
+    unsigned *ptab;    // [n_units * ngroups][tiles_per_unit + 1] start of every tile's run inside sxy, item by item
+    unsigned *item_tot;  // [ngroups][n_units] records per item of the sort kernel (zero before the project+bin launch)
+    unsigned *tot;     // [nbins] records per bin, summed over the pending chunks of the group
     float2 *cxy;       // [n_units][nblocks][region] compact (xs, ys) of (unit, K1 workgroup), bcount[unit][b] valid
     unsigned short *cbin;  // same shape: tile-in-unit of each compact record (K3 sorts by it)
     float *cm;         // same shape: per-particle mass (hydro) or nullptr
@@ -136,7 +143,23 @@ struct K1Args {
                                // exact cell boundaries left to the exact epilogue (grid_tie, slicer_device.hpp)
     // tile geometry (BinGeom)
     int tw_log2, th_log2, ntx, tiles_per_unit, units_per_plane, rows_per_unit, n_units, nbins, batch;
+    // two-level sort (sort2 != 0): the kernel sorts its records by unit (= coarse bin: a band of 2^crow_log2 tile rows of
+    // one plane) in LDS, sub-batch by sub-batch, and writes each sub-batch contiguously into its region of c1
+    int sort2, crow_log2;
+    float2 *c1;               // [nblocks][batch] records, sub-batch after sub-batch
+    unsigned *sb_off;         // [nblocks * kSubBatches] first record of every sub-batch (index into c1)
+    unsigned short *sb_start; // [nblocks * kSubBatches][kSubRow] start of every unit's run inside the sub-batch
+    unsigned *sb_n;           // [nblocks] sub-batches the workgroup wrote
+    unsigned *item_tot;       // [ngroups][n_units] records of every item of the sort kernel (zero before the launch)
 };
+// two-level sort: LDS staging of the project+bin kernel (records per workgroup between two flushes) and the most
+// sub-batches a workgroup can write: every flush but the last writes more than kStageCap - one round's records
+constexpr int kStageCap = 5632;
+constexpr int kSubBatches = 16;
+constexpr int kSort2Blocks = 16;  // project+bin workgroups whose sub-batches form one group (item) of the sort kernel
+constexpr int kMaxCoarse = 256;  // units of a pass of the two-level sort (8-bit ids in the staging area)
+constexpr int kSubRow = kMaxCoarse + 2;  // entries per row of the sub-batch table (unit starts + the end; even)
+constexpr int kMaxCoarseTiles = 256;  // tiles per unit of the two-level sort (8-bit ids in the sort kernel)
 
 // exhaustive device check of the f32 form of r / box used by k_project_bin_fast (all 2^31 non-negative floats)
 // exhaustive device check of quot_dl3 (slicer_device.hpp) for one map size; d_out9 zeroed by the caller
@@ -144,6 +167,7 @@ hipError_t launch_check_dl_quotient(double dl, unsigned *d_out9, hipStream_t s);
 hipError_t launch_check_box_quotient(double box, unsigned *d_mismatches, hipStream_t s);
 
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
+size_t project_bin_sort2_lds_bytes();
 size_t tile_lds_bytes(const BinGeom &G, int acc);
 size_t scatter_lds_bytes(const BinGeom &G, bool has_mass);
 hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_pos, const float *d_mass, uint64_t n,
@@ -153,14 +177,28 @@ hipError_t launch_bin_scan(const LaunchCfg &cfg, int nblocks, int n_planes, cons
                            const Targets &T, hipStream_t s);
 hipError_t launch_bin_scatter(const LaunchCfg &cfg, int nblocks, int n_planes, int max_workgroups, const BinGeom &G,
                               const BinWorkspace &W, const Targets &T, hipStream_t s);
+// two-level sort, second level: every item (unit, group of `slots_per_group` sub-batch slots) gathers the unit's runs
+// out of its sub-batches, sorts them by tile in LDS and writes them to a contiguous piece of sxy + its row of ptab
+size_t sort2_lds_bytes(int slots_per_group, int tiles_per_unit);
+hipError_t launch_sort2(int nblocks, int slots_per_group, int ngroups, int max_workgroups, const PassParams &P,
+                        const BinGeom &G, const BinWorkspace &W, hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
 #ifndef SLICER_MAX_PENDING
 #define SLICER_MAX_PENDING 8
 #endif
 constexpr int kMaxPending = SLICER_MAX_PENDING;
+constexpr int kMaxSortGroups = 32;  // two-level sort: items (groups of project+bin workgroups) per coarse bin and chunk
 struct PendingList {
     int n;
+    // Runs of a (unit, tile) bin over the pending chunks: chunk c contributes the runs [run0[c], run0[c + 1]) -- one
+    // (its range base[c][bin] .. base[c][bin + 1] of the one-level sort), or one per group of the two-level sort
+    // (ptab[c] != nullptr: ptab[c][(unit * ngroups[c] + g) * (tiles_per_unit + 1) + tile .. + 1]).
+    int run0[kMaxPending + 1];
+    const unsigned *ptab[kMaxPending];
+    int ngroups[kMaxPending];
+    unsigned *tot;  // two-level sort: records of every bin summed over the pending chunks (k_sort2 adds, k_build_items
+                    // reads and zeroes), or nullptr: totals from base[]
     const float2 *sxy[kMaxPending];
     const float *sm[kMaxPending];  // non-null: the chunk's sxy holds 12-byte (xs, ys, m) records (Rec3)
     const unsigned *base[kMaxPending];

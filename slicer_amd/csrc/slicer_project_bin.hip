@@ -145,6 +145,131 @@ constexpr double kMapWindow = 0x1p-41;  // s +- this must round to the same f32
 // through process_exact: slow, but the result never depends on the fast path's domain.
 constexpr unsigned kExcCap = 256;
 
+// ---- two-level sort: LDS staging of the workgroup's records (A.sort2) --------------------------------------------------
+// Instead of scattering every record to its (unit, workgroup) region with its tile attached, the workgroup collects
+// records in LDS, and whenever a round could overflow the staging area it sorts what it holds by unit (coarse bin: a
+// band of tile rows of one plane; counting sort with the per-unit rank taken when the record is staged) and writes the
+// sub-batch out as whole lines, with a small table of where each unit's run starts.  The sort kernel (k_sort2) gathers
+// a unit's runs from the sub-batches of a group of workgroups.  No per-tile histogram, no global prefix matrix.
+struct Stage {
+    float2 *rec;            // [kStageCap]
+    unsigned short *rank;   // [kStageCap] position of the record among its unit's records of this sub-batch
+    unsigned short *perm;   // [kStageCap] flush: staged index of the record that goes to sorted position p
+    unsigned char *bin;     // [kStageCap] unit
+    unsigned *cnt;          // [kMaxCoarse] records per unit since the last flush
+    unsigned *start;        // [kMaxCoarse + 2] flush, more than 64 units: exclusive prefix of cnt
+    unsigned *tot;          // [kMaxCoarse] records per unit written by this workgroup so far
+    unsigned *n;            // staged records
+};
+constexpr size_t kStageBytes = (size_t)kStageCap * (8 + 2 + 2 + 1) + 4 * (kMaxCoarse + kMaxCoarse + 2 + kMaxCoarse + 2);
+static_assert(kStageCap > kRound && kStageCap % 8 == 0 && kStageCap < 65536, "staging holds at least one round; 16-bit ranks");
+static_assert(kK1Block >= 4 * 64, "the flush gives its small serial jobs to waves 0..3");
+__device__ __forceinline__ Stage stage_of(unsigned *smem)
+{
+    Stage S;
+    S.rec = reinterpret_cast<float2 *>(smem);
+    S.rank = reinterpret_cast<unsigned short *>(S.rec + kStageCap);
+    S.perm = S.rank + kStageCap;
+    S.bin = reinterpret_cast<unsigned char *>(S.perm + kStageCap);
+    S.cnt = reinterpret_cast<unsigned *>(S.bin + kStageCap);
+    S.start = S.cnt + kMaxCoarse;
+    S.tot = S.start + kMaxCoarse + 2;
+    S.n = S.tot + kMaxCoarse;
+    return S;
+}
+
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = (unsigned)__shfl_up((int)v, d);
+        if ((int)lane_id() >= d)
+            v += y;
+    }
+    return v;
+}
+
+// Write the staged records out as one sub-batch if more than `threshold` of them wait.  Every thread of the workgroup
+// calls it at the same points; off (records this workgroup has written) and slot (sub-batches) are the same in all.
+// A wave that is alone on a piece of serial work runs it at a sixth of a SIMD's issue rate while the other workgroup of
+// the CU computes (measured: ~2 us per barrier-separated serial phase and flush), so the flush has as few phases as it
+// can: with at most 64 units (the usual pass) every wave scans the unit counts for itself -- no shared prefix table, no
+// barrier for it -- and the small jobs (table row, running totals, zeroing) go to different waves.
+__device__ __forceinline__ void stage_flush(const K1Args &A, unsigned *smem, unsigned threshold, unsigned &off,
+                                            unsigned &slot)
+{
+    const Stage St = stage_of(smem);
+    lds_barrier();  // the appends of this round are in
+    const unsigned n = *St.n;
+    if (n <= threshold)
+        return;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const unsigned lane = lane_id();
+    const int nu = A.n_units;
+    const size_t sg = (size_t)blockIdx.x * kSubBatches + slot;
+    unsigned short *row = A.sb_start + sg * (size_t)kSubRow;  // [unit] starts + the end: one or two whole lines
+    if (nu <= 64) {
+        const unsigned c = (int)lane < nu ? St.cnt[lane] : 0u;
+        const unsigned e = wave_inclusive_scan(c) - c;  // start of unit `lane` (lanes >= nu: the total)
+        for (unsigned i0 = 0; i0 < n; i0 += kK1Block) {  // (uniform trip count: the shuffle reads lanes of the whole wave;
+            const unsigned i = i0 + tid;                   //  a lane that had left the loop would answer 0)
+            const bool live = i < n;
+            const unsigned b = live ? St.bin[i] : 0u;
+            const unsigned at = (unsigned)__shfl((int)e, (int)b);
+            if (live)
+                St.perm[at + St.rank[i]] = (unsigned short)i;
+        }
+        if (wave == 1) {  // (nu may be 64: the end of the last run has no lane of its own)
+            if ((int)lane < nu)
+                row[lane] = (unsigned short)e;
+            if (lane == 0)
+                row[nu] = (unsigned short)n;
+        }
+        if (wave == 2 && (int)lane < nu)
+            St.tot[lane] += c;  // (only these lanes ever touch tot)
+    } else {
+        if (tid < 64) {  // exclusive prefix of the unit counts: four units per lane of wave 0 (nu <= 256)
+            unsigned v[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = tid * 4 + j;
+                v[j] = u < nu ? St.cnt[u] : 0u;
+                sum += v[j];
+            }
+            unsigned e = wave_inclusive_scan(sum) - sum;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = tid * 4 + j;
+                if (u < nu)
+                    St.start[u] = e;
+                e += v[j];
+            }
+            if (tid == 0)
+                St.start[nu] = n;
+        }
+        lds_barrier();
+        if (tid <= nu)
+            row[tid] = (unsigned short)St.start[tid];
+        if (tid < nu)
+            St.tot[tid] += St.cnt[tid];
+        for (unsigned i = tid; i < n; i += kK1Block)
+            St.perm[St.start[St.bin[i]] + St.rank[i]] = (unsigned short)i;
+    }
+    if (tid == 3 * 64)
+        A.sb_off[sg] = blockIdx.x * (unsigned)A.batch + off;
+    lds_barrier();  // perm complete, the unit counts are no longer read
+    if (tid < nu)
+        St.cnt[tid] = 0;
+    if (tid == 3 * 64)
+        *St.n = 0;
+    float2 *out = A.c1 + (size_t)blockIdx.x * (size_t)A.batch + off;
+    for (unsigned j = tid; j < n; j += kK1Block)
+        out[j] = St.rec[St.perm[j]];
+    off += n;
+    slot++;
+    lds_barrier();  // the staging area may be refilled
+}
+
 // binning + emission of one selected entry (xs, ys) of `plane`: cursor in (unit, workgroup)'s region, record, histogram
 // (s_hist / s_out / s_cnt: the workgroup's histogram, record cursors [kMaxUnits] and NGP selected-entry counters)
 // (gx, gy) = cell of (xs, ys), utilities.cpp:69-70
@@ -165,6 +290,26 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
     // border-ring entries of TSC (g = -1 or nn) still feed the edge pixels: binned with the clamped cell
     gx = min(max(gx, 0), nn - 1);
     gy = min(max(gy, 0), nn - 1);
+    if (A.sort2) {  // two-level sort: stage the record in LDS (s_hist is the staging area here)
+        const Stage St = stage_of(s_hist);
+        const unsigned coarse = (unsigned)plane * (unsigned)A.units_per_plane + ((unsigned)(gy >> A.th_log2) >> A.crow_log2);
+        const unsigned long long em = __ballot(emit);
+        if (em != 0ull) {  // one counter add per wave instruction: the emitting lanes take consecutive slots
+            const int lead = (int)__builtin_ctzll(em);
+            unsigned base = 0;
+            if ((int)lane_id() == lead)
+                base = atomicAdd(St.n, (unsigned)__popcll(em));
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, lead);
+            if (emit) {
+                const unsigned idx = base + (unsigned)__popcll(em & ((1ull << lane_id()) - 1ull));
+                const unsigned r = atomicAdd(&St.cnt[coarse], 1u);
+                St.rec[idx] = make_float2(xs, ys);
+                St.bin[idx] = (unsigned char)coarse;
+                St.rank[idx] = (unsigned short)r;
+            }
+        }
+        return;
+    }
     if (emit) {
         const unsigned ty = (unsigned)(gy >> A.th_log2), tx = (unsigned)(gx >> A.tw_log2);
         unsigned band = 0, trow = ty;
@@ -253,13 +398,17 @@ __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, 
 // waves (pays when few particles survive: one plane per pass keeps ~20 %); !STACK: the projection runs in place on the
 // lanes that survive (pays when most do: the four planes of a replication keep ~78 %, and the LDS traffic and the
 // write -> read round trips of the stack cost more than the idle lanes).
-template <int FACE, int SERIES, bool STACK, bool POW2>
+// SORT2: the two-level sort (staging in LDS, sub-batches sorted by unit; see Stage) instead of per-record scatter + tile
+// histogram.  Not combined with STACK (the wave stacks and the staging area do not both fit twice per CU).
+template <int FACE, int SERIES, bool STACK, bool POW2, bool SORT2>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin_fast(K1Kernarg K)
 {
+    static_assert(!(STACK && SORT2), "the two-level sort runs without the wave stacks");
     const K1Args &A = K.A;  // K.P is read through the kernarg segment by the exact epilogue only
-    extern __shared__ unsigned smem[];
-    unsigned *s_hist = smem;  // per-workgroup histogram, two 16-bit counters per word (<= 65535 records per workgroup)
-    const int hist_words = (A.nbins + 1) >> 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+    unsigned *s_hist = smem;  // per-workgroup histogram, two 16-bit counters per word (<= 65535 records per workgroup);
+                              // SORT2: the staging area (stage_of)
+    const int hist_words = SORT2 ? 0 : (A.nbins + 1) >> 1;
     const int tid = threadIdx.x;
     const unsigned lane = lane_id();
     const int wave = tid >> 6;
@@ -279,7 +428,17 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
         s_neg = 0;
         s_nexc = 0;
     }
+    if (SORT2) {
+        const Stage St = stage_of(smem);
+        if (tid < kMaxCoarse) {
+            St.cnt[tid] = 0;
+            St.tot[tid] = 0;
+        }
+        if (tid == 0)
+            *St.n = 0;
+    }
     __syncthreads();
+    unsigned st_off = 0, st_slot = 0;  // SORT2: records / sub-batches this workgroup has written (the same in all threads)
 
     const uint64_t b0 = (uint64_t)blockIdx.x * A.batch;
     const uint64_t b1 = dmin<uint64_t>(A.n, b0 + A.batch);
@@ -295,9 +454,12 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
     load_round(vec, A.pos, i0, nvalid, rx, ry, rz);
 
-    for (uint64_t r0 = w0; r0 < b1; r0 += kRound) {
+    // (SORT2: every wave runs the same number of rounds -- the flush after each round holds workgroup barriers -- so the
+    // loop ends where the workgroup's last round ends; a wave beyond the batch's end runs that round empty)
+    const uint64_t lim = SORT2 ? b1 + (w0 - b0) : b1;
+    for (uint64_t r0 = w0; r0 < lim; r0 += kRound) {
         const uint64_t i1 = i0 + kRound;
-        const bool more = r0 + kRound < b1;
+        const bool more = r0 + kRound < lim;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
         if (more)
             load_round(vec, A.pos, i1, nvalid1, nx, ny, nz);
@@ -371,6 +533,15 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             }
             lds_fence();
         }
+        if (SORT2) {  // a further round must fit the staging area
+            // The next round's positions (requested a round ago) are taken in BEFORE the flush puts its stores into the
+            // memory queue: vmcnt counts in order, so a wait for those loads issued after the stores would also wait
+            // for the stores to be acknowledged (~1-2 us per flush on the critical path).
+#pragma unroll
+            for (int k = 0; k < kPerThread; k++)
+                asm volatile("" : "+v"(nx[k]), "+v"(ny[k]), "+v"(nz[k]));
+            stage_flush(A, smem, (unsigned)(kStageCap - kRound), st_off, st_slot);
+        }
 
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
@@ -396,14 +567,54 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 s_cnt[tid] = 0;
             if (tid < kMaxUnits)
                 s_out[tid] = 0;
+            if (SORT2) {  // ... the sub-batches it has written included: it starts over
+                const Stage St = stage_of(smem);
+                if (tid < kMaxCoarse) {
+                    St.cnt[tid] = 0;
+                    St.tot[tid] = 0;
+                }
+                if (tid == 0)
+                    *St.n = 0;
+                st_off = 0;
+                st_slot = 0;
+            }
             __syncthreads();
         }
         bool neg = false;
-        for (unsigned e = tid; e < (redo ? nb : nexc); e += kK1Block)
-            neg |= process_exact(Kk, s_hist, s_out, s_cnt, redo ? e : s_exc[e], b0, out_wg, unit_stride);
+        const unsigned ne = redo ? nb : nexc;
+        // (uniform trip count: with SORT2 every step ends in the workgroup-wide flush test)
+        for (unsigned e0 = 0; e0 < ne; e0 += kK1Block) {
+            const unsigned e = e0 + tid;
+            if (e < ne)
+                neg |= process_exact(Kk, s_hist, s_out, s_cnt, redo ? e : s_exc[e], b0, out_wg, unit_stride);
+            if (SORT2)
+                stage_flush(A, smem, (unsigned)(kStageCap - kK1Block), st_off, st_slot);
+        }
         if (neg)
             s_neg = 1;
         __syncthreads();
+    }
+    if (SORT2) {
+        stage_flush(A, smem, 0u, st_off, st_slot);  // whatever is left
+        const Stage St = stage_of(smem);
+        if (tid == 0) {
+            A.sb_n[blockIdx.x] = st_slot;
+            if (s_neg)
+                atomicOr(A.neg_flag, 1);
+        }
+        // this workgroup's records per unit -> the total of its sort item (the sort kernel places the items by their
+        // prefix) and the selected-entry counters: the records, plus (NGP) the selected entries dropped as off-grid
+        if (tid < A.n_units) {
+            const unsigned c = St.tot[tid];
+            if (c) {
+                atomicAdd(&A.item_tot[(size_t)(blockIdx.x / kSort2Blocks) * A.n_units + tid], c);
+                atomicAdd(&s_cnt[tid / A.units_per_plane], c);
+            }
+        }
+        __syncthreads();
+        if (tid < A.n_planes && s_cnt[tid])
+            atomicAdd(A.nsel + 6 * tid, (unsigned long long)s_cnt[tid]);
+        return;
     }
     unsigned *row = A.hist16 + (size_t)blockIdx.x * hist_words;  // u16 [nbins] packed, row stride hist_words words
     for (int i = tid; i < hist_words; i += kK1Block)
@@ -655,6 +866,8 @@ size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass)
     return sizeof(unsigned) * (size_t)((((G.nbins + 1) >> 1) + 3) & ~3) + (size_t)kWaves * kWaveQ * 16;
 }
 
+size_t project_bin_sort2_lds_bytes() { return (kStageBytes + 15) & ~(size_t)15; }
+
 template <typename Kern>
 static hipError_t set_lds(Kern kern, size_t lds)
 {
@@ -671,24 +884,26 @@ static hipError_t launch_k1_fast(bool s9, int nb, size_t lds, const PassParams &
     K1Kernarg K;
     K.P = P;
     K.A = A;
-#define K1F_(S_, ST_, P2_)                                                            \
+#define K1F_(S_, ST_, P2_, S2_)                                                       \
     do {                                                                              \
-        auto kern = k_project_bin_fast<FACE, S_, ST_, P2_>;                           \
+        auto kern = k_project_bin_fast<FACE, S_, ST_, P2_, S2_>;                      \
         if ((e = set_lds(kern, lds)) != hipSuccess)                                   \
             return e;                                                                 \
         kern<<<nb, kK1Block, lds, s>>>(K);                                            \
     } while (0)
-#define K1F(S_, ST_)                                                                  \
+#define K1F(S_, ST_, S2_)                                                             \
     do {                                                                              \
         if (A.pow2)                                                                   \
-            K1F_(S_, ST_, true);                                                      \
+            K1F_(S_, ST_, true, S2_);                                                 \
         else                                                                          \
-            K1F_(S_, ST_, false);                                                     \
+            K1F_(S_, ST_, false, S2_);                                                \
     } while (0)
-    if (A.stack) {
-        if (s9) K1F(9, true); else K1F(15, true);
+    if (A.sort2) {  // (never with the wave stacks: the host clears `stack` when it picks the two-level sort)
+        if (s9) K1F(9, false, true); else K1F(15, false, true);
+    } else if (A.stack) {
+        if (s9) K1F(9, true, false); else K1F(15, true, false);
     } else {
-        if (s9) K1F(9, false); else K1F(15, false);
+        if (s9) K1F(9, false, false); else K1F(15, false, false);
     }
 #undef K1F_
 #undef K1F
@@ -740,8 +955,15 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_po
         A.tw_log2 = G.tw_log2, A.th_log2 = G.th_log2, A.ntx = G.ntx, A.tiles_per_unit = G.tiles_per_unit;
         A.units_per_plane = G.units_per_plane, A.rows_per_unit = G.rows_per_unit, A.n_units = G.n_units;
         A.nbins = G.nbins, A.batch = G.batch;
+        A.c1 = W.c1;
+        A.sb_off = W.sb_off;
+        A.sb_start = W.sb_start;
+        A.sb_n = W.sb_n;
+        A.item_tot = W.item_tot;
+        if (A.sort2)
+            A.stack = 0;
         const int nb = (int)((n + G.batch - 1) / G.batch);
-        const size_t lds = project_bin_lds_bytes(G, cfg.has_mass);
+        const size_t lds = A.sort2 ? project_bin_sort2_lds_bytes() : project_bin_lds_bytes(G, cfg.has_mass);
         switch (A0.face) {
         case 0: return launch_k1_fast<0>(s9, nb, lds, P, A, s);
         case 1: return launch_k1_fast<1>(s9, nb, lds, P, A, s);

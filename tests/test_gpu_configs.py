@@ -65,11 +65,13 @@ def headline_ref():
     return pos, ref
 
 
+@pytest.mark.parametrize("sort2", [0, 1])
 @pytest.mark.parametrize("accum", ["f32", "f64", "fixed64"])
-def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum):
+def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref, accum, sort2):
     # the benchmark keeps integer tile cells in the F32 / F64 modes (16384 particles per (plane, tile) bin and launch; one
     # sub-file alone sits right at the 2048 threshold): force that kernel here
     S.set_option("k4_int", 2)
+    S.set_option("sort2", sort2)
     pos, ref = headline_ref
     n = len(pos)
     d = S.to_device(pos)
@@ -98,6 +100,8 @@ def test_headline_subfile_4096_tsc_four_planes_binned_vs_oracle(S, headline_ref,
     S.free(d)
     # the benchmark's tile kernel: integer LDS cells in the F32 / F64 modes (bit 6), the fast project+bin kernel (bit 4)
     assert bool(S.algo_mask() & 64) == (accum != "fixed64") and S.algo_mask() & 16
+    assert bool(S.algo_mask() & 128) == bool(sort2)   # the two-level sort ran iff asked for (this pass qualifies)
+    S.set_option("sort2", 0)
     gate = max(1e-6, 2.0 * U24 * np.sqrt(kmax))
     print(f"headline 4096^2 TSC 4 planes BINNED accum={accum}: max_rel_dpixel {worst:.3e} (k_max {kmax}, gate {gate:.2e})")
     assert worst <= gate

@@ -30,7 +30,7 @@ U24 = 2.0 ** -24
 
 
 OPTION_KEYS = ("k4_int", "tile_log2", "tile_h_log2", "bin_batch", "unit_rows", "k3_per_cu", "k1_general", "k1_stack",
-               "ngp_general", "dl_quot")
+               "ngp_general", "dl_quot", "sort2")
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +56,15 @@ def S(S0):
         S0.plane_begin(8, 1.0, [0.0], [1.0])
     for k, v in saved.items():
         S0.set_option(k, v)
+
+
+@pytest.fixture(params=[0, 1], ids=["sort1", "sort2"])
+def sort_levels(request, S):
+    """The one-level sort (default) and the two-level sort (option sort2: project+bin sorts by coarse bin in LDS, k_sort2
+    by tile, the tile kernel walks a table of runs) -- where a pass qualifies for the latter (fast project+bin kernel,
+    constant mass, most particles selected); algo mask bit 7 tells whether it ran."""
+    S.set_option("sort2", request.param)
+    return request.param
 
 
 @pytest.fixture(params=[2, 0], ids=["int_cells", "f64_cells"])
@@ -293,7 +302,7 @@ def test_large_fov_uses_libm_path(S):
 
 @pytest.mark.parametrize("npix", [64, 256, 100, 1000])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_ngp_bit_exact(S, npix, algo):
+def test_ngp_bit_exact(S, sort_levels, npix, algo):
     files = [one_type_file(150000)]
     ref_tot, ref_toti, nsel = run_oracle(files, npix, 0.25, 3.0, 3.5, ngp=True)
     (tot, toti, cnt), = run_gpu(S, files, npix, 0.25, 3.0, 3.5, ngp=True, algo=algo)
@@ -303,7 +312,7 @@ def test_ngp_bit_exact(S, npix, algo):
 
 
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_ngp_multi_file_multi_type_bit_exact(S, algo):
+def test_ngp_multi_file_multi_type_bit_exact(S, sort_levels, algo):
     """A5: three ragged files, five species, odd type offsets (unaligned device pointers)."""
     files, first = [], 0
     for ff in range(3):
@@ -323,7 +332,7 @@ def test_ngp_multi_file_multi_type_bit_exact(S, algo):
 @pytest.mark.parametrize("npix,n", [(64, 200000), (256, 400000), (100, 100000)])
 @pytest.mark.parametrize("accum", [slicer_amd.ACC_F32, slicer_amd.ACC_F64, slicer_amd.ACC_FIXED64])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_tsc_vs_oracle(S, tile_cells, npix, n, accum, algo):
+def test_tsc_vs_oracle(S, sort_levels, tile_cells, npix, n, accum, algo):
     files = [one_type_file(n)]
     fov, ld, ld2 = 0.25, 3.0, 3.5
     ref_tot, ref_toti, nsel = run_oracle(files, npix, fov, ld, ld2)
@@ -376,7 +385,7 @@ def test_tsc_weights_bitwise_through_fixed_point(S, npix, algo):
 
 
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_fixed64_is_bitwise_reproducible_and_linear(S, algo):
+def test_fixed64_is_bitwise_reproducible_and_linear(S, sort_levels, algo):
     """Order-independent accumulation: two runs agree bitwise, and a file split in two sub-files
     gives the same map as the joint file (linearity of the deposit, exact in fixed point)."""
     npix, fov, ld, ld2 = 256, 0.25, 3.0, 3.5
@@ -424,7 +433,7 @@ def test_tsc_multi_type_multi_file(S, algo):
 
 @pytest.mark.parametrize("npix", [128, 296])
 @pytest.mark.parametrize("algo", [slicer_amd.ALGO_DIRECT, slicer_amd.ALGO_BINNED])
-def test_multi_plane_pass_equals_single_plane_calls(S, algo, npix):
+def test_multi_plane_pass_equals_single_plane_calls(S, sort_levels, algo, npix):
     """Four planes of one box replication in one pass == four createDensityMaps-style calls (NGP: bitwise).
     npix = 296 gives an odd number of tiles per plane (19 x 19 NGP, 19 x 37 TSC): the odd planes' bins then start in
     the middle of a packed histogram word, which the sort kernel handles on a separate path."""
@@ -443,7 +452,7 @@ def test_multi_plane_pass_equals_single_plane_calls(S, algo, npix):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_configurations_binned_path(S, seed):
+def test_random_configurations_binned_path(S, sort_levels, seed):
     """Randomised differential check of the binned pipeline: map size (power of two or not), number of planes and
     their (contiguous or gapped) slabs, field of view, face, signs, centre, file split and particle count are drawn at
     random; NGP maps and counters must equal the oracle's bit for bit, and the FIXED64 TSC maps those of the fused
@@ -628,7 +637,7 @@ def test_baseline_config1_256cubed_1024_tsc_four_planes(S):
     print(f"config1: max per-pixel relative difference {worst:.2e}")
 
 
-def test_heavy_tile_is_split_and_stays_exact(S):
+def test_heavy_tile_is_split_and_stays_exact(S, sort_levels):
     """Half of the particles inside one pixel (a halo core): the tile kernel splits that (plane, tile) bin over
     several workgroups (k_build_items).  NGP stays bit-exact against the oracle, fixed-point TSC is identical
     between the fused global-atomic kernel and the binned path, f32 TSC stays within the usual bar."""
@@ -676,7 +685,7 @@ def test_golden_vectors(S, tile_cells, name, algo):
             assert np.array_equal(g_toti[t].view(np.uint32), toti[t].view(np.uint32))
 
 
-def test_large_maps_8192_ngp_exact_and_16384_properties(S):
+def test_large_maps_8192_ngp_exact_and_16384_properties(S, sort_levels):
     """BASELINE configs[4] shape (16384^2): more than 8192 (plane, tile) bins, so every plane is split into units of a
     few tile rows (BinGeom) and the binned path still runs -- asserted through slicer_plane_algo_mask; 8192^2 runs it
     with whole-plane units.  NGP at 8192^2 is compared bit for bit with the
@@ -1014,14 +1023,14 @@ def test_fast_and_general_project_bin_kernels_agree(S, general):
         lo = rnd["rcase"]
         lds, ld2s = [lo, lo + 0.25, lo + 0.5, lo + 0.75], [lo + 0.25, lo + 0.5, lo + 0.75, lo + 1.0]
         out = run_gpu(S, [f], 512, 0.25, lds, ld2s, ngp=True, algo=slicer_amd.ALGO_BINNED, rnd=rnd)
-        assert S.algo_mask() >> 4 == (2 if (general or not qualifies) else 1)
+        assert S.algo_mask() >> 4 & 3 == (2 if (general or not qualifies) else 1)
         for p in range(4):
             ref_tot, _, nsel = run_oracle([f], 512, 0.25, lds[p], ld2s[p], ngp=True, rnd=rnd)
             assert np.array_equal(out[p][2], nsel)
             assert np.array_equal(out[p][0].view(np.uint32), ref_tot.view(np.uint32)), (rnd, p)
 
 
-def test_fast_project_bin_kernel_redoes_a_batch_with_too_many_exceptions(S):
+def test_fast_project_bin_kernel_redoes_a_batch_with_too_many_exceptions(S, sort_levels):
     """The fast project+bin kernel notes particles outside its domain (raw coordinate -0.0, negative, beyond the box)
     in a 256-entry LDS list; a workgroup that sees more than that discards what it emitted and runs its WHOLE batch
     through the exact code (slicer_project_bin.hip, `redo`).  400 such particles inside one batch (8192 particles at
@@ -1214,7 +1223,7 @@ def test_grid_arithmetic_of_maps_that_are_not_a_power_of_two(S, npix):
 
 
 @pytest.mark.parametrize("npix", [300, 1000, 4000])
-def test_fast_project_bin_kernel_on_maps_that_are_not_a_power_of_two(S, npix):
+def test_fast_project_bin_kernel_on_maps_that_are_not_a_power_of_two(S, sort_levels, npix):
     """The fast project+bin kernel takes any map size: the cell of an entry is floor(xs * npix) from the exact f64
     product, entries exactly on a cell boundary go to its exact epilogue.  NGP bit for bit against the oracle (four planes,
     f32 centre, coordinates on the box faces included), and fixed-point TSC identical to the fused kernel's."""
