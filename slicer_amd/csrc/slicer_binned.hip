@@ -495,11 +495,7 @@ __global__ __launch_bounds__(kS2Block, 4) void k_sort2(const float2 *__restrict_
                     int r = first[(q - p0) >> 6];
                     while (q >= r_off[r + 1])
                         r++;
-#if defined(SLICER_S3X) && (SLICER_S3X & 1)  // timing experiment only
-                    rec[k] = make_float2(0.001f * (float)(q & 1023u), 0.0007f * (float)(q & 1023u));
-#else
                     rec[k] = c1[r_src[r] + (q - r_off[r])];
-#endif
                 }
 #pragma unroll
                 for (int k = 0; k < kS2R; k++) {
@@ -553,10 +549,8 @@ __global__ __launch_bounds__(kS2Block, 4) void k_sort2(const float2 *__restrict_
                         scol[at] = (unsigned char)t;
                     }
                 lds_barrier();
-#if !defined(SLICER_S3X) || !(SLICER_S3X & 2)
                 for (unsigned i = tid; i < nsub; i += kS2Block)
                     sxy[adj[scol[i]] + i] = stage[i];
-#endif
                 if (p1 < total)
                     lds_barrier();  // the next window overwrites the staging area
             }

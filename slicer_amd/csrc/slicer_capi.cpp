@@ -678,7 +678,10 @@ int k1_fast_args(slicer_handle h, const PassParams &P, const BinGeom &G, int nbl
     A.eps_ra = 2e-6f;
     A.k_dec = ceil_to_f32(tl * std::sqrt(1.0 + (double)A.k_ra * (double)A.k_ra) * (1.0 + 3e-5));
     A.eps_dec = ceil_to_f32(tl * 2.2e-6 + 1e-6);
-    A.series_max = P.series_max;
+    // both series of the fast kernel run on tangents: |tan ra| <= k_ra and |tan dec| = |X| / sqrt(Y^2 + Z^2) <= |X| / Z <=
+    // k_dec (plus the pre-test's absolute slack) for every entry that passes the pre-test; entries beyond the chosen
+    // range (15 terms: 0.3125) are left to the exact epilogue by the kernel
+    A.series_max = (!(h->desc.debug_flags & 2) && (double)A.k_dec * 1.001 + 1e-4 < kSeriesMax9) ? kSeriesMax9 : kSeriesMax15;
     A.lim = P.lim;
     A.inv_fov = P.inv_fov;
     A.nn_f = P.nn_f;

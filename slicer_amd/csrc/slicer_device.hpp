@@ -214,6 +214,115 @@ __device__ __forceinline__ double atan_small(double t)
     return fma(t * z, p, t);
 }
 
+// Two arctangents at once through ONE pass over the coefficients: every coefficient is materialised once (two s_mov)
+// and feeds two independent v_fma_f64 -- half the scalar moves and wait states of two separate series, and two
+// independent dependency chains per Horner step.  Used by the fast project+bin kernel, which takes BOTH angles as
+// arctangents: ra = atan(Y / Z) and dec = atan(X / sqrt(Y^2 + Z^2)) (= asin(X / d), utilities.cpp:23-25, in exact
+// arithmetic; its results are only trusted inside the error window of project_emit either way).
+template <unsigned long long C>
+__device__ __forceinline__ void fma_sc2(double ra, double wa, double rb, double wb, double &oa, double &ob)
+{
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)(C & 0xFFFFFFFFull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(C >> 32)));
+    const double c = __hiloint2double((int)hi, (int)lo);
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(oa) : "v"(ra), "v"(wa), "s"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ob) : "v"(rb), "v"(wb), "s"(c));
+}
+#define FMA_SC2(ra, wa, rb, wb, c) fma_sc2<dbits(c)>(ra, wa, rb, wb, ra, rb)
+
+template <int N>
+__device__ __forceinline__ void atan_small_pair(double ta, double tb, double &outa, double &outb)
+{
+    static_assert(N == 9 || N == 15, "term counts with a proven range");
+    const double za = ta * ta, wa = za * za, zb = tb * tb, wb = zb * zb;
+    double pea, poa, peb, pob;
+    if (N == 15) {
+        pea = peb = -0x1.0842108421084p-5;  // -1/31
+        poa = pob = 0x1.1a7b9611a7b96p-5;   // +1/29
+        FMA_SC2(pea, wa, peb, wb, -0x1.2f684bda12f68p-5);  // -1/27
+        FMA_SC2(poa, wa, pob, wb, 0x1.47ae147ae147bp-5);   // +1/25
+        FMA_SC2(pea, wa, peb, wb, -0x1.642c8590b2164p-5);  // -1/23
+        FMA_SC2(poa, wa, pob, wb, 0x1.8618618618618p-5);   // +1/21
+        FMA_SC2(pea, wa, peb, wb, -0x1.af286bca1af28p-5);  // -1/19
+        FMA_SC2(poa, wa, pob, wb, 0x1.e1e1e1e1e1e1ep-5);   // +1/17
+        FMA_SC2(pea, wa, peb, wb, -0x1.1111111111111p-4);  // -1/15
+        FMA_SC2(poa, wa, pob, wb, 0x1.3b13b13b13b14p-4);   // +1/13
+    } else {
+        pea = peb = -0x1.af286bca1af28p-5;  // -1/19
+        poa = pob = 0x1.e1e1e1e1e1e1ep-5;   // +1/17
+        FMA_SC2(pea, wa, peb, wb, -0x1.1111111111111p-4);  // -1/15
+        FMA_SC2(poa, wa, pob, wb, 0x1.3b13b13b13b14p-4);   // +1/13
+    }
+    FMA_SC2(pea, wa, peb, wb, -0x1.745d1745d1746p-4);  // -1/11
+    FMA_SC2(poa, wa, pob, wb, 0x1.c71c71c71c71cp-4);   // +1/9
+    FMA_SC2(pea, wa, peb, wb, -0x1.2492492492492p-3);  // -1/7
+    FMA_SC2(poa, wa, pob, wb, 0x1.999999999999ap-3);   // +1/5
+    FMA_SC2(pea, wa, peb, wb, -0x1.5555555555555p-2);  // -1/3
+    const double pa = fma(poa, za, pea), pb = fma(pob, zb, peb);
+    outa = fma(ta * za, pa, ta);
+    outb = fma(tb * zb, pb, tb);
+}
+
+// The same for four arguments (two particles' two angles): one pass over the coefficients feeds four independent
+// chains -- a quarter of the scalar moves per arctangent, and enough independent fp64 work in ONE wave to cover the
+// latency of a dependent v_fma_f64 without help from other waves.
+template <unsigned long long C>
+__device__ __forceinline__ void fma_sc4(double (&r)[4], const double (&w)[4])
+{
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)(C & 0xFFFFFFFFull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(C >> 32)));
+    const double c = __hiloint2double((int)hi, (int)lo);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r[i]) : "v"(r[i]), "v"(w[i]), "s"(c));
+}
+#define FMA_SC4(r, w, c) fma_sc4<dbits(c)>(r, w)
+
+template <int N>
+__device__ __forceinline__ void atan_small_quad(const double (&t)[4], double (&out)[4])
+{
+    static_assert(N == 9 || N == 15, "term counts with a proven range");
+    double z[4], w[4], pe[4], po[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        z[i] = t[i] * t[i];
+        w[i] = z[i] * z[i];
+    }
+    if (N == 15) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            pe[i] = -0x1.0842108421084p-5;  // -1/31
+            po[i] = 0x1.1a7b9611a7b96p-5;   // +1/29
+        }
+        FMA_SC4(pe, w, -0x1.2f684bda12f68p-5);  // -1/27
+        FMA_SC4(po, w, 0x1.47ae147ae147bp-5);   // +1/25
+        FMA_SC4(pe, w, -0x1.642c8590b2164p-5);  // -1/23
+        FMA_SC4(po, w, 0x1.8618618618618p-5);   // +1/21
+        FMA_SC4(pe, w, -0x1.af286bca1af28p-5);  // -1/19
+        FMA_SC4(po, w, 0x1.e1e1e1e1e1e1ep-5);   // +1/17
+        FMA_SC4(pe, w, -0x1.1111111111111p-4);  // -1/15
+        FMA_SC4(po, w, 0x1.3b13b13b13b14p-4);   // +1/13
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            pe[i] = -0x1.af286bca1af28p-5;  // -1/19
+            po[i] = 0x1.e1e1e1e1e1e1ep-5;   // +1/17
+        }
+        FMA_SC4(pe, w, -0x1.1111111111111p-4);  // -1/15
+        FMA_SC4(po, w, 0x1.3b13b13b13b14p-4);   // +1/13
+    }
+    FMA_SC4(pe, w, -0x1.745d1745d1746p-4);  // -1/11
+    FMA_SC4(po, w, 0x1.c71c71c71c71cp-4);   // +1/9
+    FMA_SC4(pe, w, -0x1.2492492492492p-3);  // -1/7
+    FMA_SC4(po, w, 0x1.999999999999ap-3);   // +1/5
+    FMA_SC4(pe, w, -0x1.5555555555555p-2);  // -1/3
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        out[i] = fma(t[i] * z[i], fma(po[i], z[i], pe[i]), t[i]);
+}
+
 // ---- correctly rounded sqrt and quotient without the range scaling ---------------------------------------------
 // The compiler's IEEE sequences (v_rsq_f64 / v_rcp_f64 + FMA iterations) wrap the same iterations in exponent
 // scaling (v_div_scale, v_div_fmas, v_div_fixup, v_ldexp + class tests) that only matters for operands near the

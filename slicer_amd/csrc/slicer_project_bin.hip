@@ -38,13 +38,16 @@ namespace slicer {
 
 namespace {
 
+// 512 threads at 4 waves per SIMD: two workgroups (16 waves) per CU and 128 VGPRs per lane.  Round 2 ran 768 threads at
+// 6 waves per SIMD (80 VGPRs); round 3 measured the same speed at the lower occupancy (108 vs 109 us: the kernel does not
+// live off waves in flight) and spends the registers on two particles per lane in the projection (project_emit2).
 #ifndef SLICER_K1_BLOCK
-#define SLICER_K1_BLOCK 768
+#define SLICER_K1_BLOCK 512
 #endif
 #ifndef SLICER_K1_WAVES_PER_SIMD
-#define SLICER_K1_WAVES_PER_SIMD 6
+#define SLICER_K1_WAVES_PER_SIMD 4
 #endif
-constexpr int kK1Block = SLICER_K1_BLOCK;  // 12 waves, two workgroups per CU at 32768 particles each
+constexpr int kK1Block = SLICER_K1_BLOCK;  // 8 waves, two workgroups per CU at 32768 particles each
 #ifndef SLICER_K1_PER_THREAD
 #define SLICER_K1_PER_THREAD 4
 #endif
@@ -54,34 +57,43 @@ constexpr int kRound = kK1Block * kPerThread;
 constexpr int kWaves = kK1Block / 64;
 constexpr int kWaveQ = 64 * kPerThread + 64;  // stack capacity per wave: one round + a remainder < 64
 
-__device__ __forceinline__ void load_round(bool vec, const float *__restrict__ pos, uint64_t i0, int nvalid,
-                                           float (&rx)[kPerThread], float (&ry)[kPerThread], float (&rz)[kPerThread])
+// One lane's particles of a round as they lie in the POS block: raw[3 k + a] = coordinate a of its particle k.
+// Loaded by buffer loads through a descriptor of the WORKGROUP'S batch (base = its first particle, size = its bytes):
+// the hardware range check returns 0 for every dword beyond the batch, so the ragged end of a chunk needs no second
+// load path -- and with a single path there is no merge point at which the compiler reconciles register layouts by
+// moving freshly loaded registers around.  It did, with a vector and a scalar path: a v_mov right behind the loads
+// means waiting for the next round's positions the moment they have been requested, and the "prefetch" overlapped
+// nothing (round 3; the rounds of a wave then cost a full memory latency each).
+struct RawRound {
+    float v[3 * kPerThread];
+};
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t batch_rsrc(const float *pos, uint64_t b0, uint64_t b1)
 {
-    if (vec && nvalid == kPerThread) {  // 16-byte aligned block: four particles = three dwordx4 loads
-        if constexpr (kPerThread == 4) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(pos + 3 * i0);
-            const float4 a = p4[0], b = p4[1], c = p4[2];
-            rx[0] = a.x; ry[0] = a.y; rz[0] = a.z;
-            rx[1] = a.w; ry[1] = b.x; rz[1] = b.y;
-            rx[2] = b.z; ry[2] = b.w; rz[2] = c.x;
-            rx[3] = c.y; ry[3] = c.z; rz[3] = c.w;
-        } else {  // two particles = three dwordx2 loads (the lane's 24 bytes are 8-byte aligned)
-            const float2 *p2 = reinterpret_cast<const float2 *>(pos + 3 * i0);
-            const float2 a = p2[0], b = p2[1], c = p2[2];
-            rx[0] = a.x; ry[0] = a.y; rz[0] = b.x;
-            rx[1] = b.y; ry[1] = c.x; rz[1] = c.y;
-        }
+    // raw buffer (stride 0): num_records in bytes; word 3 as for gfx90a / gfx94x / gfx950 raw 32-bit data
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(pos + 3 * b0), 0, (int)((b1 - b0) * 12), 0x00020000);
+}
+
+// particles [i, i + kPerThread) of the batch (i relative to the batch's first particle)
+__device__ __forceinline__ void load_round(__amdgpu_buffer_rsrc_t rsrc, unsigned i, RawRound &R)
+{
+    const unsigned off = i * 12u;
+    if constexpr (kPerThread == 4) {
+        const v4u_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        const v4u_t b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
+        const v4u_t c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
+        R.v[0] = __uint_as_float(a.x); R.v[1] = __uint_as_float(a.y); R.v[2] = __uint_as_float(a.z);
+        R.v[3] = __uint_as_float(a.w); R.v[4] = __uint_as_float(b.x); R.v[5] = __uint_as_float(b.y);
+        R.v[6] = __uint_as_float(b.z); R.v[7] = __uint_as_float(b.w); R.v[8] = __uint_as_float(c.x);
+        R.v[9] = __uint_as_float(c.y); R.v[10] = __uint_as_float(c.z); R.v[11] = __uint_as_float(c.w);
     } else {
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            if (k < nvalid) {
-                rx[k] = pos[3 * (i0 + k) + 0];
-                ry[k] = pos[3 * (i0 + k) + 1];
-                rz[k] = pos[3 * (i0 + k) + 2];
-            } else {
-                rx[k] = ry[k] = rz[k] = 0.f;
-            }
-        }
+        const v2u_t a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        const v2u_t b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 8, 0, 0);
+        const v2u_t c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16, 0, 0);
+        R.v[0] = __uint_as_float(a.x); R.v[1] = __uint_as_float(a.y); R.v[2] = __uint_as_float(b.x);
+        R.v[3] = __uint_as_float(b.y); R.v[4] = __uint_as_float(c.x); R.v[5] = __uint_as_float(c.y);
     }
 }
 
@@ -355,19 +367,14 @@ __device__ SLICER_SLOWPATH bool process_exact(const K1Kernarg *Kk, unsigned *s_h
 }
 
 // Fast projection (A3) of one selected entry per lane + emission; entries it cannot decide are noted for the epilogue.
-template <int SERIES, bool POW2>
-__device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
-                                             unsigned *s_exc, unsigned *s_nexc, bool have, float ex, float ey, float ez,
-                                             unsigned tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
+// After the series: accept / note for the exact epilogue / emit one entry.  sn, tn: tan(dec), tan(ra); dec, ra.
+template <bool POW2>
+__device__ __forceinline__ void decide_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
+                                            unsigned *s_exc, unsigned *s_nexc, bool have, float ez, double sn, double tn,
+                                            double dec, double ra, unsigned tag, uint64_t b0, float2 *out_wg,
+                                            unsigned unit_stride)
 {
     float xs = 0.f, ys = 0.f;
-    // A3 (densitymaps.cpp:382-386, utilities.cpp:23-25) to a few ulp: q = X / d and t = Y / Z through one cubic step on
-    // the hardware reciprocal (square root); asin / atan by the series of slicer_device.hpp
-    const double X = (double)ex - 0.5, Y = (double)ey - 0.5, Z = (double)ez;
-    const double S = fma(X, X, fma(Y, Y, Z * Z));
-    const double sn = X * rsqrt_fast(S);
-    const double tn = Y * rcp_fast(Z);
-    const double dec = asin_small<SERIES>(sn), ra = atan_small<SERIES>(tn);
     const double adec = fabs(dec), ara = fabs(ra);
     // undecided: outside the series' range (tiny z), or within the error window of the FOV limit or of an f32 rounding
     // tie of a map coordinate
@@ -392,6 +399,46 @@ __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, 
         s_exc[min(atomicAdd(s_nexc, 1u), kExcCap - 1)] = tag >> 3;
     const bool valid = have && !undecided && adec <= A.lim && ara <= A.lim;
     emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, gx, gy, tag >> 3, b0, out_wg, unit_stride);
+}
+
+template <int SERIES, bool POW2>
+__device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
+                                             unsigned *s_exc, unsigned *s_nexc, bool have, float ex, float ey, float ez,
+                                             unsigned tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
+{
+    // A3 (densitymaps.cpp:382-386, utilities.cpp:23-25) to a few ulp: both angles as arctangents through one pass over
+    // the series' coefficients (atan_small_pair): ra = atan(Y / Z), dec = asin(X / d) = atan(X / sqrt(Y^2 + Z^2)); the
+    // quotients through one cubic step on the hardware reciprocal (square root)
+    const double X = (double)ex - 0.5, Y = (double)ey - 0.5, Z = (double)ez;
+    const double R2 = fma(Y, Y, Z * Z);
+    const double sn = X * rsqrt_fast(R2);  // tan(dec)
+    const double tn = Y * rcp_fast(Z);     // tan(ra)
+    double dec, ra;
+    atan_small_pair<SERIES>(sn, tn, dec, ra);
+    decide_emit<POW2>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have, ez, sn, tn, dec, ra, tag, b0, out_wg, unit_stride);
+}
+
+// Two entries per lane at once: the four arctangents share one pass over the coefficients (atan_small_quad) and give
+// the wave four independent fp64 chains.
+template <int SERIES, bool POW2>
+__device__ __forceinline__ void project_emit2(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
+                                              unsigned *s_exc, unsigned *s_nexc, const bool (&have)[2],
+                                              const float (&ex)[2], const float (&ey)[2], const float (&ez)[2],
+                                              const unsigned (&tag)[2], uint64_t b0, float2 *out_wg, unsigned unit_stride)
+{
+    double t[4], ang[4];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const double X = (double)ex[j] - 0.5, Y = (double)ey[j] - 0.5, Z = (double)ez[j];
+        const double R2 = fma(Y, Y, Z * Z);
+        t[2 * j] = X * rsqrt_fast(R2);   // tan(dec)
+        t[2 * j + 1] = Y * rcp_fast(Z);  // tan(ra)
+    }
+    atan_small_quad<SERIES>(t, ang);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        decide_emit<POW2>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have[j], ez[j], t[2 * j], t[2 * j + 1], ang[2 * j],
+                          ang[2 * j + 1], tag[j], b0, out_wg, unit_stride);
 }
 
 // STACK: survivors of the slab / pre-test are compacted through the wave stack so that the projection runs on full
@@ -448,11 +495,11 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     unsigned top = 0;  // entries on this wave's stack (wave-uniform)
 
     const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
-    float rx[kPerThread], ry[kPerThread], rz[kPerThread];
-    float nx[kPerThread], ny[kPerThread], nz[kPerThread];
+    RawRound cur, nxt;
+    const __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(A.pos, b0, b1);
     uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
     int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
-    load_round(vec, A.pos, i0, nvalid, rx, ry, rz);
+    load_round(rsrc, (unsigned)(i0 - b0), cur);
 
     // (SORT2: every wave runs the same number of rounds -- the flush after each round holds workgroup barriers -- so the
     // loop ends where the workgroup's last round ends; a wave beyond the batch's end runs that round empty)
@@ -461,62 +508,72 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
         const uint64_t i1 = i0 + kRound;
         const bool more = r0 + kRound < lim;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
-        if (more)
-            load_round(vec, A.pos, i1, nvalid1, nx, ny, nz);
+        load_round(rsrc, (unsigned)(i1 - b0), nxt);  // (beyond the batch: zeros, no memory access)
 
-        // ---- transform, slab select, conservative FOV pre-test, push ----
+        // ---- transform, slab select, conservative FOV pre-test; push (STACK) or project two particles at a time ----
+        static_assert(kPerThread % 2 == 0, "particles are projected in pairs");
 #pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            // face permutation (gadget2io.cpp:222-252): output axis a reads source axis perm[a]
-            constexpr int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
-            const float src[3] = {rx[k], ry[k], rz[k]};
-            const float s0 = src[perms[FACE][0]], s1 = src[perms[FACE][1]], s2 = src[perms[FACE][2]];
-            // q = RN32(r / box): reciprocal product, exact residual, correction (k_check_box_quotient vouches for
-            // every r whose q lies in [2^-100, 1]; smaller q cannot influence the results below, see k1_fast_args);
-            // (float)(sgn * ((double)r / box)) = sgn * q      gadget2io.cpp:204-206
-            const float g0 = s0 * A.rb, g1 = s1 * A.rb, g2 = s2 * A.rb;
-            const float q0 = fmaf(fmaf(-g0, A.boxf, s0), A.rb, g0);
-            const float q1 = fmaf(fmaf(-g1, A.boxf, s1), A.rb, g1);
-            const float q2 = fmaf(fmaf(-g2, A.boxf, s2), A.rb, g2);
-            // domain of this path: +0 <= q <= 1 on all three axes as ONE unsigned test on the bit patterns (positive
-            // floats order like their bits; -0.0, negatives and NaN have the top bit set or exceed 0x3F800000)
-            const bool off = max(max(__float_as_uint(q0), __float_as_uint(q1)), __float_as_uint(q2)) > kQHi;
-            // first wrap (gadget2io.cpp:209-220) for q in [0, 1]: sgn = +1 leaves q, sgn = -1 gives 1 + (-q), one f32
-            // operation either way: fma(q, sgn, sgn < 0 ? 1 : 0)  (q = 0 on a mirrored axis travels as -0.0 in the
-            // reference and comes out of the second wrap as RN(1 - c), which is what 1.0 - c gives here).  Recentre +
-            // second wrap (gadget2io.cpp:254-269): w in [0, 1] and c in (0, 1] give d in [-1, 1), so only
-            // "d < 0 -> 1 + d" can fire; (float)((double)w - c) is the f32 difference because c is an f32 value.
-            const float d0 = fmaf(q0, A.ws[0], A.wo[0]) - A.c0f[0];
-            const float d1 = fmaf(q1, A.ws[1], A.wo[1]) - A.c0f[1];
-            const float d2 = fmaf(q2, A.ws[2], A.wo[2]) - A.c0f[2];
-            const float x = d0 < 0.0f ? 1.0f + d0 : d0;
-            const float y = d1 < 0.0f ? 1.0f + d1 : d1;
-            const float z = (d2 < 0.0f ? 1.0f + d2 : d2) + A.rcase;  // gadget2io.cpp:270
-            // slab of this particle (densitymaps.cpp:374): the planes of one box replication are consecutive slabs, so
-            // plane = number of inner thresholds passed (zlo[p >= n_planes] = +inf)
-            const bool in = z >= A.zlo[0] && z < A.zlast;
-            const int plane = (z >= A.zlo[1] ? 1 : 0) + (z >= A.zlo[2] ? 1 : 0) + (z >= A.zlo[3] ? 1 : 0);
-            // Conservative f32 pre-test of the FOV cut: true only if the entry certainly fails |ra| <= lim or
-            // |dec| <= lim.  |ra| > lim <=> |Y| > Z tan(lim); given that this does not hold, sqrt(Y^2 + Z^2) <=
-            // Z sec(lim)(1 + margin), so |X| > Z tan(lim) sec(lim)(1 + margin) implies |dec| > lim.  The margins
-            // (3e-5 relative, ~2e-6 absolute) dwarf every f32 rounding here; z = 0 only yields "outside", which is what
-            // the reference decides for it too (angles of +-pi/2 or NaN).
-            const bool outside = fabsf(y - 0.5f) > fmaf(z, A.k_ra, A.eps_ra) || fabsf(x - 0.5f) > fmaf(z, A.k_dec, A.eps_dec);
-            const bool live = k < nvalid;
-            const bool sel = live && !off && in && !outside;
-            if (live && off)  // rare: noted for the exact epilogue
-                s_exc[min(atomicAdd(&s_nexc, 1u), kExcCap - 1)] = (unsigned)(i0 + k - b0);
-            const unsigned long long mask = __ballot(sel);
-            const unsigned tag = (unsigned)plane | ((unsigned)(i0 + k - b0) << 3);
-            if (STACK) {
-                if (sel) {
-                    const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                    q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
+        for (int k0 = 0; k0 < kPerThread; k0 += 2) {
+            float px[2], py[2], pz[2];
+            bool psel[2];
+            unsigned ptag[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int k = k0 + j;
+                // face permutation (gadget2io.cpp:222-252): output axis a reads source axis perm[a]
+                constexpr int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
+                const float src[3] = {cur.v[3 * k], cur.v[3 * k + 1], cur.v[3 * k + 2]};
+                const float s0 = src[perms[FACE][0]], s1 = src[perms[FACE][1]], s2 = src[perms[FACE][2]];
+                // q = RN32(r / box): reciprocal product, exact residual, correction (k_check_box_quotient vouches for
+                // every r whose q lies in [2^-100, 1]; smaller q cannot influence the results below, see k1_fast_args);
+                // (float)(sgn * ((double)r / box)) = sgn * q      gadget2io.cpp:204-206
+                const float g0 = s0 * A.rb, g1 = s1 * A.rb, g2 = s2 * A.rb;
+                const float q0 = fmaf(fmaf(-g0, A.boxf, s0), A.rb, g0);
+                const float q1 = fmaf(fmaf(-g1, A.boxf, s1), A.rb, g1);
+                const float q2 = fmaf(fmaf(-g2, A.boxf, s2), A.rb, g2);
+                // domain of this path: +0 <= q <= 1 on all three axes as ONE unsigned test on the bit patterns (positive
+                // floats order like their bits; -0.0, negatives and NaN have the top bit set or exceed 0x3F800000)
+                const bool off = max(max(__float_as_uint(q0), __float_as_uint(q1)), __float_as_uint(q2)) > kQHi;
+                // first wrap (gadget2io.cpp:209-220) for q in [0, 1]: sgn = +1 leaves q, sgn = -1 gives 1 + (-q), one f32
+                // operation either way: fma(q, sgn, sgn < 0 ? 1 : 0)  (q = 0 on a mirrored axis travels as -0.0 in the
+                // reference and comes out of the second wrap as RN(1 - c), which is what 1.0 - c gives here).  Recentre +
+                // second wrap (gadget2io.cpp:254-269): w in [0, 1] and c in (0, 1] give d in [-1, 1), so only
+                // "d < 0 -> 1 + d" can fire; (float)((double)w - c) is the f32 difference because c is an f32 value.
+                const float d0 = fmaf(q0, A.ws[0], A.wo[0]) - A.c0f[0];
+                const float d1 = fmaf(q1, A.ws[1], A.wo[1]) - A.c0f[1];
+                const float d2 = fmaf(q2, A.ws[2], A.wo[2]) - A.c0f[2];
+                const float x = d0 < 0.0f ? 1.0f + d0 : d0;
+                const float y = d1 < 0.0f ? 1.0f + d1 : d1;
+                const float z = (d2 < 0.0f ? 1.0f + d2 : d2) + A.rcase;  // gadget2io.cpp:270
+                // slab of this particle (densitymaps.cpp:374): the planes of one box replication are consecutive slabs,
+                // so plane = number of inner thresholds passed (zlo[p >= n_planes] = +inf)
+                const bool in = z >= A.zlo[0] && z < A.zlast;
+                const int plane = (z >= A.zlo[1] ? 1 : 0) + (z >= A.zlo[2] ? 1 : 0) + (z >= A.zlo[3] ? 1 : 0);
+                // Conservative f32 pre-test of the FOV cut: true only if the entry certainly fails |ra| <= lim or
+                // |dec| <= lim.  |ra| > lim <=> |Y| > Z tan(lim); given that this does not hold, sqrt(Y^2 + Z^2) <=
+                // Z sec(lim)(1 + margin), so |X| > Z tan(lim) sec(lim)(1 + margin) implies |dec| > lim.  The margins
+                // (3e-5 relative, ~2e-6 absolute) dwarf every f32 rounding here; z = 0 only yields "outside", which is
+                // what the reference decides for it too (angles of +-pi/2 or NaN).
+                const bool outside =
+                    fabsf(y - 0.5f) > fmaf(z, A.k_ra, A.eps_ra) || fabsf(x - 0.5f) > fmaf(z, A.k_dec, A.eps_dec);
+                const bool live = k < nvalid;
+                const bool sel = live && !off && in && !outside;
+                if (live && off)  // rare: noted for the exact epilogue
+                    s_exc[min(atomicAdd(&s_nexc, 1u), kExcCap - 1)] = (unsigned)(i0 + k - b0);
+                const unsigned tag = (unsigned)plane | ((unsigned)(i0 + k - b0) << 3);
+                if (STACK) {
+                    const unsigned long long mask = __ballot(sel);
+                    if (sel) {
+                        const unsigned slot = top + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                        q4[slot] = make_float4(x, y, z, __uint_as_float(tag));
+                    }
+                    top += (unsigned)__popcll(mask);
                 }
-                top += (unsigned)__popcll(mask);
-            } else if (mask != 0ull) {
-                project_emit<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, sel, x, y, z, tag, b0, out_wg, unit_stride);
+                px[j] = x, py[j] = y, pz[j] = z, psel[j] = sel, ptag[j] = tag;
             }
+            if (!STACK && __ballot(psel[0] || psel[1]) != 0ull)
+                project_emit2<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, psel, px, py, pz, ptag, b0, out_wg,
+                                            unit_stride);
         }
         if (STACK) {
             lds_fence();
@@ -538,17 +595,12 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             // memory queue: vmcnt counts in order, so a wait for those loads issued after the stores would also wait
             // for the stores to be acknowledged (~1-2 us per flush on the critical path).
 #pragma unroll
-            for (int k = 0; k < kPerThread; k++)
-                asm volatile("" : "+v"(nx[k]), "+v"(ny[k]), "+v"(nz[k]));
+            for (int k = 0; k < 3 * kPerThread; k++)
+                asm volatile("" : "+v"(nxt.v[k]));
             stage_flush(A, smem, (unsigned)(kStageCap - kRound), st_off, st_slot);
         }
 
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            rx[k] = nx[k];
-            ry[k] = ny[k];
-            rz[k] = nz[k];
-        }
+        cur = nxt;
         i0 = i1;
         nvalid = nvalid1;
     }
@@ -667,11 +719,11 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     unsigned top = 0;
 
     const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
-    float rx[kPerThread], ry[kPerThread], rz[kPerThread];
-    float nx[kPerThread], ny[kPerThread], nz[kPerThread];
+    RawRound cur, nxt;
+    const __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(pos, b0, b1);
     uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
     int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
-    load_round(vec != 0, pos, i0, nvalid, rx, ry, rz);
+    load_round(rsrc, (unsigned)(i0 - b0), cur);
 
     // pops 64 entries (or the rest when `flush`) and runs the exact projection on them
     auto drain = [&](bool flush) {
@@ -725,15 +777,14 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
         const uint64_t i1 = i0 + kRound;
         const bool more = r0 + kRound < b1;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
-        if (more)
-            load_round(vec != 0, pos, i1, nvalid1, nx, ny, nz);
+        load_round(rsrc, (unsigned)(i1 - b0), nxt);  // (beyond the batch: zeros, no memory access)
 
         if (!REP) {
             // ---- transform, slab select, conservative FOV pre-test, push ----
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) {
                 float x, y, z;
-                transform(rx[k], ry[k], rz[k], P, x, y, z);
+                transform(cur.v[3 * k], cur.v[3 * k + 1], cur.v[3 * k + 2], P, x, y, z);
                 const bool live = k < nvalid;
                 neg |= live & ((x < 0.0f) | (y < 0.0f) | (z < 0.0f));  // densitymaps.cpp:334
                 // slabs are disjoint on this path (checked on the host); unused slots are empty intervals
@@ -766,7 +817,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             int plane[kPerThread];
 #pragma unroll
             for (int k = 0; k < kPerThread; k++) {
-                transform(rx[k], ry[k], rz[k], P, x[k], y[k], z[k]);
+                transform(cur.v[3 * k], cur.v[3 * k + 1], cur.v[3 * k + 2], P, x[k], y[k], z[k]);
                 const bool live = k < nvalid;
                 neg |= live & ((x[k] < 0.0f) | (y[k] < 0.0f) | (z[k] < 0.0f));  // densitymaps.cpp:334
                 int pl = -1;
@@ -801,12 +852,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             }
         }
 
-#pragma unroll
-        for (int k = 0; k < kPerThread; k++) {
-            rx[k] = nx[k];
-            ry[k] = ny[k];
-            rz[k] = nz[k];
-        }
+        cur = nxt;
         i0 = i1;
         nvalid = nvalid1;
     }
@@ -937,8 +983,9 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_po
 {
     const bool vec = (reinterpret_cast<uintptr_t>(d_pos) & 15u) == 0 && (G.batch % 4) == 0;
     const bool pow2 = P.pow2 != 0;
-    const bool s9 = P.series_max < 0.2;  // every survivor of the pre-test is inside the 9-term range
+    bool s9 = P.series_max < 0.2;  // every survivor of the pre-test is inside the 9-term range
     if (fast) {
+        s9 = A0.series_max < 0.2;  // (the fast kernel's own bound: both of its series run on tangents)
         K1Args A = A0;
         A.pos = d_pos;
         A.mass = cfg.has_mass ? d_mass : nullptr;
