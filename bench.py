@@ -66,7 +66,10 @@ def parse():
                     help="auto: steps (strong scaling, whole steps per rank, finished maps sent to rank 0) when N > 1")
     ap.add_argument("--streams", type=int, default=1,
                     help="snapshots in flight per GPU: consecutive steps alternate between this many handles, each on "
-                         "its own HIP stream (kernels of different steps may then run concurrently)")
+                         "its own HIP stream.  With more than one the job is timed on ONE stream first (`single_stream`; "
+                         "the per-kernel durations of `roofline` / `kernels` belong to that run) and `value` is the "
+                         "multi-stream run.  Measured gain of 2 over 1: about 2 %, inside the run-to-run scatter "
+                         "(DESIGN.md S5), hence the default of 1")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--reduce-algo", default="rooted", choices=["rooted", "rs_gather", "p2p"],
                     help="--shard files: the per-plane rank sum as one library reduce per map (rooted), as reduce-scatter "
@@ -296,14 +299,15 @@ def main():
     class Layout:
         """One way of spreading the job over the ranks: its handles, its step function, its timed run."""
 
-        def __init__(self, shard, reduce_algo="rooted"):
+        def __init__(self, shard, reduce_algo="rooted", streams=None):
             self.shard, self.reduce_algo = shard, reduce_algo
+            streams = a.streams if streams is None else streams
             self.reduce_steps = shard == "files" and use_dist
             self.gather_steps = shard == "steps" and use_dist
             self.overlap = (self.reduce_steps or self.gather_steps) and not a.no_overlap
             # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and
             # workspace and works on its own stream; RCCL runs on torch.distributed's communication stream.
-            self.n_handles = max(2 if self.overlap else 1, a.streams)
+            self.n_handles = max(2 if self.overlap else 1, streams)
             self.handles = [slicer_amd.Slicer(local_rank, max_chunk=chunk) for _ in range(self.n_handles)]
             self.streams = ([torch.cuda.Stream() for _ in range(self.n_handles)] if self.n_handles > 1
                             else [torch.cuda.current_stream()])
@@ -453,10 +457,22 @@ def main():
             self.my_dep = my_dep
             return dt, tot_dep, tot_in
 
-    L = Layout(shard, a.reduce_algo)
-    dt, tot_dep, tot_in = L.run()
+    # With several snapshots in flight the kernels of different steps share the GPU and their individual durations say
+    # nothing about the kernels themselves.  So the job is timed twice: first on ONE stream (`single_stream`, the number
+    # the per-kernel HIP-event durations add up to; the profile and parity phases below run on that layout too), then
+    # with `--streams` snapshots in flight -- that second run is `value`.
+    single_stream, Lmain = None, None
+    if a.streams > 1 and not use_dist:
+        L = Layout(shard, a.reduce_algo, streams=1)
+        dt1, dep1, in1 = L.run()
+        single_stream = {"value": dep1 / dt1, "ms_per_step": 1e3 * dt1 / a.steps, "n_in_per_s": in1 / dt1, "streams": 1}
+    else:
+        L = Layout(shard, a.reduce_algo)
+        dt, tot_dep, tot_in = L.run()
+        Lmain = L
     reduce_steps, gather_steps, overlap = L.reduce_steps, L.gather_steps, L.overlap
-    n_handles, handles, my_files, my_dep, algo_mask = L.n_handles, L.handles, L.my_files, L.my_dep, L.algo_mask
+    algo_mask = L.algo_mask
+    n_handles, handles, my_files, my_dep = L.n_handles, L.handles, L.my_files, L.my_dep
     S0 = handles[0]
     step, local_step, drain = L.step, L.local_step, L.drain
 
@@ -527,6 +543,13 @@ def main():
                   "algo_mask": S0.algo_mask()}
         del buf
 
+    if Lmain is None:  # the timed run proper: `--streams` snapshots in flight
+        L.close()
+        L = Lmain = Layout(shard, a.reduce_algo)
+        dt, tot_dep, tot_in = L.run()
+        algo_mask = L.algo_mask
+        n_handles = L.n_handles
+
     # ---- end to end: page-cached format-2 file -> C++ createDensityMaps adapter -> maps in host memory
     e2e = None
     if rank == 0 and world == 1 and (a.e2e == "on" or (a.e2e == "auto" and a.cpu != "off")):
@@ -575,6 +598,7 @@ def main():
                             f"resident in HBM, {a.npix}^2 {a.mas.upper()}, {len(lds)} lens planes per pass, "
                             f"{'clustered' if a.clustered else 'uniform'}",
                 "shard": shard, "algo": a.algo, "accum": a.accum, "algo_mask": algo_mask,
+                "streams": max(1, a.streams) if not use_dist else None,
                 "reduce_algo": a.reduce_algo if reduce_steps else None,
                 "reduce_layout": reduce_layout,
                 "collective": (("per-plane sum to rank 0 in the accumulator type over RCCL, " if reduce_steps else
@@ -591,6 +615,10 @@ def main():
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": 1e3 * dom_ms / max(dom_n, 1),
                          "whole_step_traffic": traffic_step},
             "kernels": kernels,
+            "kernels_measured": "HIP events on one stream, in extra untimed steps right after the single-stream timed run (with "
+                                "several snapshots in flight the kernels of different steps share the GPU); they add up to "
+                                "single_stream.ms_per_step, or to ms_per_step under --streams 1",
+            "single_stream": single_stream,
             "max_rel_dpixel": parity["max_rel_dpixel"] if parity else None,
             "parity": parity,
             "e2e": e2e,

@@ -32,6 +32,10 @@ def test_one_gpu_line_has_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["config"]["reduce_layout"] is None
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # one snapshot in flight by default; with --streams 2 the same steps on one stream are reported next to `value`
+    assert d["config"]["streams"] == 1 and d["single_stream"] is None
+    two = _bench(SMALL + ["--streams", "2"])
+    assert two["config"]["streams"] == 2 and two["single_stream"]["value"] > 0 and two["value"] > 0
 
 
 def test_one_run_times_the_step_layout_and_the_per_plane_reduce_layout():
