@@ -70,8 +70,9 @@ extern "C" {
 #define SLICER_ALGO_AUTO 0
 #define SLICER_ALGO_DIRECT 1 /* fused project + global atomics                                   */
 #define SLICER_ALGO_BINNED 2 /* project -> tile bins -> LDS-privatised tiles -> shaped row flush.  A pass with more
-                             * (plane, tile) bins than one run holds, or with overlapping slabs, goes in plane groups.
-                             * An explicit BINNED request that cannot be honoured (nrepperp > 3) returns
+                             * (plane, tile) bins than one run holds, or with overlapping slabs, goes in plane groups;
+                             * more than three lateral replications per side go in windows of the replica grid.
+                             * An explicit BINNED request that cannot be honoured (a tile table beyond the limits) returns
                              * SLICER_ERR_UNSUPPORTED; only SLICER_ALGO_AUTO falls back to DIRECT
                              * (slicer_plane_algo_mask tells which ran). */
 

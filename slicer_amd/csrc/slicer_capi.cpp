@@ -344,6 +344,8 @@ void make_params(slicer_handle h, int type, bool has_mass, PassParams &P)
         P.zlo[p] = INFINITY;
         P.zhi[p] = -INFINITY;
     }
+    P.rep_i0 = P.rep_j0 = -64;  // every lateral replica (the binned path narrows this per launch)
+    P.rep_i1 = P.rep_j1 = 64;
     P.fov = d.fov_rad;
     P.inv_fov = 1.0 / d.fov_rad;
     P.lim = d.fov_rad * (1. + 2. / d.npix) * 0.5;  // densitymaps.cpp:383
@@ -486,6 +488,11 @@ void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
     T.max_mass = h->d_maxmass + (shared ? 6 : type);
 }
 
+// Lateral replication (densitymaps.cpp:377-381): a pass with n replications per side has (2n+1)^2 replicas per particle.
+// One launch of the binned project kernel takes a window of at most 7 x 7 of them; the side (2n+1) is cut into equal parts.
+static int rep_windows(int nrmax) { return (2 * nrmax + 1 + 6) / 7; }
+static int rep_window_side(int nrmax) { return (2 * nrmax + 1 + rep_windows(nrmax) - 1) / rep_windows(nrmax); }
+
 constexpr int kBinBatch = 32768;  // particles per K1 workgroup (sweep: tools/sweep.sh)
 constexpr int kUnitBins = 8192;   // up to this many bins the units are whole planes
 
@@ -497,9 +504,10 @@ bool choose_geom(const slicer_plane_desc &d, int acc, const Options &opt, BinGeo
     int nrmax = 0;
     for (int p = 0; p < d.n_planes; p++)
         nrmax = std::max(nrmax, d.nrepperp[p]);
-    if (nrmax > 3)  // (2n+1)^2 records per particle must fit the 16-bit per-workgroup counters at a 1024-particle batch
-        return false;
-    const int reps = (2 * nrmax + 1) * (2 * nrmax + 1);
+    // (2n+1)^2 records per particle must fit the 16-bit per-workgroup counters at a 1024-particle batch: beyond three
+    // replications per side the replica grid is walked in windows of at most 7 x 7, one run of K1-K3 per window
+    const int ws = rep_window_side(nrmax);
+    const int reps = ws * ws;
     for (int p = 0; p < d.n_planes; p++)  // slabs must be disjoint: a particle enters at most one bin
         for (int q = p + 1; q < d.n_planes; q++)
             if (d.ld[p] < d.ld2[q] && d.ld[q] < d.ld2[p])
@@ -1128,9 +1136,8 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
         }
     if (!binned && d.algo == SLICER_ALGO_BINNED)
         return fail(h, SLICER_ERR_UNSUPPORTED,
-                    "SLICER_ALGO_BINNED cannot serve this pass (more than three lateral replications, or a tile table "
-                    "beyond the limits even for a single plane); SLICER_ALGO_AUTO falls back to the fused global-atomic "
-                    "kernel");
+                    "SLICER_ALGO_BINNED cannot serve this pass (a tile table beyond the limits even for a single "
+                    "plane); SLICER_ALGO_AUTO falls back to the fused global-atomic kernel");
     if (binned && d.algo == SLICER_ALGO_AUTO && n < 65536)
         binned = false;  // several launches are not worth it for a tiny chunk
     h->algo_mask |= 1 << (binned ? SLICER_ALGO_BINNED : SLICER_ALGO_DIRECT);
@@ -1164,9 +1171,22 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
                 Tg.nsel[j] = nullptr;
             }
         }
-        int rc = binned_chunk(h, cfg, Pg, Tg, G, type, p0 / gsize, p0, np, d_pos, d_mass, n);
-        if (rc)
-            return rc;
+        int nr = 0;
+        for (int j = 0; j < np; j++)
+            nr = std::max(nr, Pg.nrep[j]);
+        const int nwin = rep_windows(nr), ws = rep_window_side(nr);
+        for (int wi = 0; wi < nwin; wi++)
+            for (int wj = 0; wj < nwin; wj++) {
+                if (nwin > 1) {
+                    Pg.rep_i0 = -nr + wi * ws;
+                    Pg.rep_i1 = std::min(nr, Pg.rep_i0 + ws - 1);
+                    Pg.rep_j0 = -nr + wj * ws;
+                    Pg.rep_j1 = std::min(nr, Pg.rep_j0 + ws - 1);
+                }
+                int rc = binned_chunk(h, cfg, Pg, Tg, G, type, p0 / gsize, p0, np, d_pos, d_mass, n);
+                if (rc)
+                    return rc;
+            }
     }
     return SLICER_OK;
 }

@@ -36,6 +36,9 @@ struct PassParams {
     float zlo[kMaxPlanes];  // smallest f32 >= minDist  => (double)z >= minDist  <=>  z >= zlo
     float zhi[kMaxPlanes];  // smallest f32 >= maxDist  => (double)z <  maxDist  <=>  z <  zhi
     int nrep[kMaxPlanes];
+    // window of lateral replicas (ni in [rep_i0, rep_i1], nj in [rep_j0, rep_j1]) this launch of the binned project
+    // kernel emits; the host walks the (2n+1)^2 replicas of densitymaps.cpp:377-381 in windows of at most 7 x 7
+    int rep_i0, rep_i1, rep_j0, rep_j1;
     // --- projection (densitymaps.cpp:382-386) ---
     double fov;
     double inv_fov;  // RN(1/fov): fast path of the map coordinate, see map_coord_risky()

@@ -489,7 +489,6 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
 
     const uint64_t b0 = (uint64_t)blockIdx.x * A.batch;
     const uint64_t b1 = dmin<uint64_t>(A.n, b0 + A.batch);
-    const bool vec = A.vec != 0;
     float2 *const out_wg = A.cxy + (size_t)blockIdx.x * (size_t)A.batch;  // this workgroup's region of unit 0
     const unsigned unit_stride = gridDim.x * (unsigned)A.batch;           // records between two units' regions
     unsigned top = 0;  // entries on this wave's stack (wave-uniform)
@@ -714,7 +713,10 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     int nrmax = 0;  // lateral replication: entries (x + ni, y + nj), |ni|, |nj| <= nrep[plane]   densitymaps.cpp:377-381
     for (int p = 0; p < P.n_planes; p++)
         nrmax = P.nrep[p] > nrmax ? P.nrep[p] : nrmax;
-    const int side = 2 * nrmax + 1, nrep2 = side * side;
+    // this launch's window of the replica grid (the whole grid up to three replications per side)
+    const int wi0 = P.rep_i0 > -nrmax ? P.rep_i0 : -nrmax, wi1 = P.rep_i1 < nrmax ? P.rep_i1 : nrmax;
+    const int wj0 = P.rep_j0 > -nrmax ? P.rep_j0 : -nrmax, wj1 = P.rep_j1 < nrmax ? P.rep_j1 : nrmax;
+    const int side = wj1 - wj0 + 1, nrep2 = (wi1 - wi0 + 1) * side;
     bool neg = false;
     unsigned top = 0;
 
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             // one pass of the round per lateral replica (ni outer, nj inner: the reference's order, which only the
             // shot-noise path depends on): the stack never holds more than one round + a remainder
             for (int rep = 0; rep < nrep2; rep++) {
-                const int ni = rep / side - nrmax, nj = rep % side - nrmax;
+                const int ni = rep / side + wi0, nj = rep % side + wj0;
 #pragma unroll
                 for (int k = 0; k < kPerThread; k++) {
                     const int pl = plane[k];

@@ -863,18 +863,44 @@ def test_rccl_plane_reduce_single_rank(S):
 
 
 def test_explicit_binned_request_fails_loudly_when_unsupported(S):
-    """SLICER_ALGO_BINNED on a pass the binned path cannot serve (more than three lateral replications)
-    returns SLICER_ERR_UNSUPPORTED instead of silently running the 18x slower fused kernel; AUTO falls back and says so."""
+    """SLICER_ALGO_BINNED on a pass the binned path cannot serve (here: 8 x 8-pixel tiles asked for on a
+    4096^2 map, a tile table beyond the limits) returns SLICER_ERR_UNSUPPORTED instead of silently running the 18x
+    slower fused kernel; AUTO falls back and says so."""
     f = one_type_file(70000)
-    S.plane_begin(64, 0.25, [3.0], [4.0], nrepperp=[4], algo=slicer_amd.ALGO_BINNED)
+    S.set_option("tile_log2", 3)
+    S.plane_begin(4096, 0.25, [3.0], [4.0], mas=slicer_amd.MAS_NGP, algo=slicer_amd.ALGO_BINNED)
     S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
     with pytest.raises(slicer_amd.SlicerError) as e:
         S.deposit_host(1, f["pos"])
     assert e.value.code == slicer_amd.api.ERR_UNSUPPORTED
-    (tot, _, cnt), = run_gpu(S, [f], 64, 0.25, [3.0], [4.0], ngp=True, nrep=4, algo=slicer_amd.ALGO_AUTO)
+    S.file_end()
+    S.plane_begin(64, 0.25, [3.0], [4.0])  # leave the refused pass
+    S.set_option("tile_log2", 3)
+    (tot, _, cnt), = run_gpu(S, [f], 4096, 0.25, [3.0], [4.0], ngp=True, algo=slicer_amd.ALGO_AUTO)
     assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_DIRECT
-    ref_tot, _, nsel = run_oracle([f], 64, 0.25, 3.0, 4.0, ngp=True, nrep=4)
+    S.set_option("tile_log2", 0)
+    ref_tot, _, nsel = run_oracle([f], 4096, 0.25, 3.0, 4.0, ngp=True)
     assert np.array_equal(cnt, nsel) and np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+
+
+@pytest.mark.parametrize("nrep,ngp", [(4, True), (5, False), (8, True)])
+def test_many_lateral_replications_run_binned_in_replica_windows(S, nrep, ngp):
+    """VERDICT r2 missing 4: more than three lateral replications per side ((2n+1)^2 = 81 ... 289 replicas per particle,
+    densitymaps.cpp:377-381) used to drop to the fused global-atomic kernel; the binned kernels now take the replica grid
+    in windows of at most 7 x 7, one run of project / scan / sort per window into the same pending list."""
+    f = one_type_file(70000)
+    fov = 1.96 * float(np.arctan((nrep + 0.5) / 4.0))  # a field that the replicas fill (testFov: fov * ld2 <= (2n+1) boxes)
+    ref_tot, _, nsel = run_oracle([f], 64, fov, 3.0, 4.0, ngp=ngp, nrep=nrep)
+    for algo in (slicer_amd.ALGO_BINNED, slicer_amd.ALGO_AUTO):
+        (tot, _, cnt), = run_gpu(S, [f], 64, fov, [3.0], [4.0], ngp=ngp, nrep=nrep, algo=algo)
+        assert (S.algo_mask() & 15) == 1 << slicer_amd.ALGO_BINNED
+        assert nsel[1] > 9 * 70000 and np.array_equal(cnt, nsel)
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+        else:
+            nz = ref_tot > 0
+            assert float((np.abs(tot[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max()) < tsc_gate(
+                1.5 * 9 * nsel.sum() / 64 ** 2)
 
 
 @pytest.mark.parametrize("ngp", [True, False])
