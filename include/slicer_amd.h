@@ -140,9 +140,24 @@ const char *slicer_last_error(slicer_handle h); /* valid until the next call on 
  *   k1_stack     fast project+bin kernel: -1 automatic, 0 / 1 project in place / through the wave stack
  *   ngp_general  1: no in-tile NGP fold                      dl_quot      0: no reciprocal-product grid quotient
  *   sort2        1: the two-level sort wherever a pass qualifies (default 0: the one-level sort)
+ *   thin_host    1: shot-noise deviates (snopt > 0) drawn by libc rand() on the host, one call per selected entry;
+ *                default 0: the process-global rand() stream continues on the device (slicer_libc_rand_supported)
  * Unknown keys return SLICER_ERR_ARG. */
 int slicer_set_option(slicer_handle h, const char *key, int32_t value);
 int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
+
+/* Shot-noise thinning (InputParams.snopt > 0) consumes the process-global libc rand() stream, one deviate per selected
+ * entry (densitymaps.cpp:393).  The library continues that stream on the device -- it reads the generator state, jumps
+ * and generates there, and installs the advanced state before the depositing call returns (single plane) or before
+ * slicer_plane_flush / finalize / read returns (several planes: the chunks are replayed plane by plane), so the caller's
+ * later rand() calls see exactly the stream position the reference would leave.  This needs glibc's default TYPE_3
+ * generator (no initstate() with another size by the process) and passes a layout self-check on a private state
+ * array: 1 if so, 0 if thinning falls back to rand() calls on the host (same deviates, ~100x slower).  No GPU needed. */
+int slicer_libc_rand_supported(void);
+/* The process-global generator state as 31 words, oldest first (x[n-31] ... x[n-1] of x[n] = x[n-31] + x[n-3],
+ * rand() = x[n] >> 1): read, and install.  Test hooks of the above; SLICER_ERR_UNSUPPORTED if not supported. */
+int slicer_libc_rand_state_get(uint32_t *v31);
+int slicer_libc_rand_state_set(const uint32_t *v31);
 
 /* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = handle-owned. */
 int slicer_set_stream(slicer_handle h, void *hip_stream);
@@ -182,7 +197,8 @@ int slicer_plane_device_counts(slicer_handle h, int plane, uint64_t **d_counts);
  * binned path used (4: the f32-transform fast variant, 5: the general one; see slicer_project_bin.hip); bit 6: a tile
  * kernel launch kept its tiles as integer (u64) cells (constant-mass TSC, F32 / F64 accumulators, enough records per
  * tile; option k4_int = 0 / 2 forbids / forces them -- a tuning and test knob); bit 7: a chunk went through the two-level
- * sort (project+bin kernel sorts by coarse bin in LDS, k_sort2 by tile; option sort2 = 1 allows it). */
+ * sort (project+bin kernel sorts by coarse bin in LDS, k_sort2 by tile; option sort2 = 1 allows it); bit 8: shot-noise
+ * deviates came from the device continuation of the libc stream. */
 int slicer_plane_algo_mask(slicer_handle h, int32_t *mask);
 /* Synchronise and report the negativity guard (densitymaps.cpp:334-345) without copying maps: SLICER_OK or
  * SLICER_ERR_NEGATIVE_COORD.  Callers that hand the device maps on (cross-rank reduce) call this first. */

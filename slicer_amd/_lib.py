@@ -42,6 +42,9 @@ SYMBOLS = {
     "slicer_last_error": (C.c_char_p, [_H]),
     "slicer_set_option": (C.c_int, [_H, C.c_char_p, C.c_int32]),
     "slicer_get_option": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_int32)]),
+    "slicer_libc_rand_supported": (C.c_int, []),
+    "slicer_libc_rand_state_get": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "slicer_libc_rand_state_set": (C.c_int, [C.POINTER(C.c_uint32)]),
     "slicer_set_stream": (C.c_int, [_H, C.c_void_p]),
     "slicer_plane_begin": (C.c_int, [_H, C.POINTER(PlaneDesc)]),
     "slicer_file_begin": (C.c_int, [_H, C.POINTER(FileDesc)]),

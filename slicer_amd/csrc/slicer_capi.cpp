@@ -56,6 +56,7 @@ struct Options {
     int k1_stack = -1;    // fast project+bin kernel: compact survivors through the wave stack (0 / 1; -1 = by slab depth)
     int ngp_general = 0;  // 1: no in-tile NGP fold (count map + k_fold_ngp)
     int dl_quot = 1;      // maps that are not a power of two wide: allow the swept reciprocal-product quotient
+    int thin_host = 0;    // 1: shot-noise deviates drawn by libc rand() on the host (0: the stream continues on the device)
     int sort2 = 0;        // 1: two-level sort (project+bin sorts by coarse bin in LDS, k_sort2 by tile) where a pass
                           // qualifies.  Off by default: it moves fewer bytes but costs more instructions
 };
@@ -75,6 +76,7 @@ const OptionName kOptionNames[] = {
     {"ngp_general", "SLICER_NGP_GENERAL", &Options::ngp_general},
     {"dl_quot", "SLICER_DL_QUOT", &Options::dl_quot},
     {"sort2", "SLICER_SORT2", &Options::sort2},
+    {"thin_host", "SLICER_THIN_HOST", &Options::thin_host},
 };
 
 struct slicer_handle_s {
@@ -130,6 +132,10 @@ struct slicer_handle_s {
     unsigned *d_sweep = nullptr;
     DevBuf w_tcounts, w_tbase, w_urand;  // shot-noise thinning (snopt > 0)
     std::vector<float> h_urand;
+    // libc's rand() stream on the device (slicer_rand.hip): jump tables, the 31-word state, wave start states
+    DevBuf w_randtab, w_randstate, w_randwaves;
+    bool rand_tab_ready = false;
+    bool rand_on_device = false;  // between thin_rng_begin and thin_rng_end the device holds the stream
     // snopt > 0 with several planes in one pass: the reference draws its deviates plane by plane (outer loop of
     // createDensityMaps' caller), so the chunks are kept on the device and deposited plane-major when the pass ends
     struct ThinChunk {
@@ -856,12 +862,56 @@ int flush_pending(slicer_handle h)
     return SLICER_OK;
 }
 
+// The libc stream moves to the device for a run of thinned chunks: thin_rng_begin reads the process-global generator
+// state and uploads it, thin_rng_end brings the advanced state back and installs it (one synchronisation).  False from
+// begin: the stream stays on the host (option thin_host, a generator other than glibc's TYPE_3, or the layout check of
+// slicer_rand.hip failed) and thin_chunk draws with rand() as the reference does.
+bool thin_rng_begin(slicer_handle h, int &rc)
+{
+    rc = SLICER_OK;
+    if (h->opt.thin_host)
+        return false;
+    uint32_t v[31];
+    if (!libc_rand_grab(v))
+        return false;
+    if ((rc = ensure(h, h->w_randtab, rand_tables_bytes())) || (rc = ensure(h, h->w_randstate, 32 * 4)))
+        return false;
+    if (!h->rand_tab_ready) {
+        if (rand_tables_upload(h->w_randtab.p, h->stream) != hipSuccess) {
+            rc = fail(h, SLICER_ERR_HIP, "upload of the generator tables failed: %s", hipGetErrorString(hipGetLastError()));
+            return false;
+        }
+        h->rand_tab_ready = true;
+    }
+    if (hipMemcpyAsync(h->w_randstate.p, v, sizeof v, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {  // v is a stack array
+        rc = fail(h, SLICER_ERR_HIP, "upload of the generator state failed: %s", hipGetErrorString(hipGetLastError()));
+        return false;
+    }
+    h->rand_on_device = true;
+    return true;
+}
+
+int thin_rng_end(slicer_handle h)
+{
+    if (!h->rand_on_device)
+        return SLICER_OK;
+    h->rand_on_device = false;
+    uint32_t v[31];
+    HIPCHK(h, hipMemcpyAsync(v, h->w_randstate.p, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!libc_rand_put(v))
+        return fail(h, SLICER_ERR_STATE, "the process changed its libc generator during a thinned pass");
+    return SLICER_OK;
+}
+
 // Shot-noise thinning of one chunk into plane slot 0 of (P, T).
 int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg &cfg, const float *d_pos,
                const float *d_mass, uint64_t n)
 {
-    // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device,
-    // draw on the host from the process-global stream (exactly what the reference consumes), deposit.
+    // densitymaps.cpp:387-397: one libc rand() per selected entry, in selection order.  Count on the device, then
+    // either continue the process-global stream on the device (thin_rng_begin) or draw on the host from it -- the
+    // same deviates either way, exactly what the reference consumes -- and deposit.
     P.series_max = kSeriesMax15;  // no pre-test on this path either
     const uint64_t nchunks = (n + 63) / 64;
     int rc;
@@ -872,9 +922,29 @@ int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg 
         HIPCHK(h, launch_thin_count(d_pos, n, P, (unsigned *)h->w_tcounts.p, (unsigned long long *)h->w_tbase.p,
                                     h->d_neg, h->stream));
     }
+    const double pw = std::pow(2, h->desc.snopt);
+    const unsigned long long *d_nsel = (unsigned long long *)h->w_tbase.p + nchunks;
+    const uint64_t reps = (uint64_t)(2 * P.nrep[0] + 1) * (uint64_t)(2 * P.nrep[0] + 1);
+    if (h->rand_on_device) {
+        // at most one draw per (particle, replica); with lateral replicas the buffer is sized by the real count
+        unsigned long long max_draws = n * reps;
+        if (reps > 1) {
+            HIPCHK(h, hipMemcpyAsync(&max_draws, d_nsel, sizeof max_draws, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        if ((rc = ensure(h, h->w_urand, std::max<size_t>(max_draws, 1) * 4)) ||
+            (rc = ensure(h, h->w_randwaves, rand_wave_states_bytes(max_draws))))
+            return rc;
+        ProfScope ps(h, KN_DIRECT);
+        HIPCHK(h, launch_rand_deviates(d_nsel, (uint32_t *)h->w_randstate.p, (uint32_t *)h->w_randwaves.p,
+                                       h->w_randtab.p, (float *)h->w_urand.p, max_draws, h->stream));
+        HIPCHK(h, launch_thin_deposit(cfg, d_pos, d_mass, n, P, T, (const unsigned long long *)h->w_tbase.p,
+                                      (const float *)h->w_urand.p, 1. / pw, pw, h->stream));
+        h->algo_mask |= (1 << 3) | (1 << 8);
+        return SLICER_OK;
+    }
     unsigned long long nsel = 0;
-    HIPCHK(h, hipMemcpyAsync(&nsel, (unsigned long long *)h->w_tbase.p + nchunks, sizeof nsel,
-                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&nsel, d_nsel, sizeof nsel, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->h_urand.resize(nsel);
     for (unsigned long long k = 0; k < nsel; k++)
@@ -883,7 +953,6 @@ int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg 
         return rc;
     if (nsel)
         HIPCHK(h, hipMemcpyAsync(h->w_urand.p, h->h_urand.data(), nsel * 4, hipMemcpyHostToDevice, h->stream));
-    const double pw = std::pow(2, h->desc.snopt);
     {
         ProfScope ps(h, KN_DIRECT);
         HIPCHK(h, launch_thin_deposit(cfg, d_pos, d_mass, n, P, T, (const unsigned long long *)h->w_tbase.p,
@@ -939,6 +1008,7 @@ int thin_replay(slicer_handle h)
     const slicer_plane_desc &d = h->desc;
     const slicer_file_desc file_saved = h->file;
     int rc = SLICER_OK;
+    thin_rng_begin(h, rc);  // (false: the deviates come from the host loop)
     for (int p = 0; p < d.n_planes && !rc; p++) {
         size_t ci = 0;
         for (size_t f = 0; f < h->thin_files.size() && !rc; f++) {
@@ -967,6 +1037,8 @@ int thin_replay(slicer_handle h)
                 rc = fold_file_plane(h, p);
         }
     }
+    const int rce = thin_rng_end(h);
+    rc = rc ? rc : rce;
     h->file = file_saved;
     for (int t = 0; t < 6; t++)
         h->file_mode[t] = 0;
@@ -1087,8 +1159,16 @@ int deposit_device_chunk(slicer_handle h, int type, const float *d_pos, const fl
     fill_targets(h, type, has_mass, T);
     LaunchCfg cfg{d.mas == SLICER_MAS_NGP ? kNGP : kTSC, acc_kind(d, has_mass), has_mass};
     if (d.snopt > 0) {
-        if (d.n_planes == 1)
-            return thin_chunk(h, P, T, cfg, d_pos, d_mass, n);
+        if (d.n_planes == 1) {
+            if (d.mas == SLICER_MAS_NGP)
+                ngp_spoil_file(h, type);  // counts into the global map: the file's fold is k_fold_ngp's, not the tile kernel's
+            int rc = SLICER_OK;
+            thin_rng_begin(h, rc);
+            if (!rc)
+                rc = thin_chunk(h, P, T, cfg, d_pos, d_mass, n);
+            const int rce = thin_rng_end(h);  // the host's stream is current again before the call returns
+            return rc ? rc : rce;
+        }
         // several planes: keep the chunk, thin_replay deposits it once per plane in the reference's order
         slicer_handle_s::ThinChunk c{};
         c.file = (int)h->thin_files.size();
@@ -1330,7 +1410,7 @@ int slicer_destroy(slicer_handle h)
     if (h->d_sweep)
         (void)hipFree(h->d_sweep);
     for (DevBuf *b : {&h->w_cxy, &h->w_cbin, &h->w_cm, &h->w_hist, &h->w_hist16, &h->w_total, &h->w_bcount, &h->w_items,
-                      &h->w_tcounts, &h->w_tbase, &h->w_urand, &h->w_c1, &h->w_sboff, &h->w_sbstart, &h->w_sbn})
+                      &h->w_tcounts, &h->w_tbase, &h->w_urand, &h->w_randtab, &h->w_randstate, &h->w_randwaves, &h->w_c1, &h->w_sboff, &h->w_sbstart, &h->w_sbn})
         release(*b);
     for (auto &Q : h->pg) {
         release(Q.w_tot);
@@ -1384,6 +1464,26 @@ int slicer_get_option(slicer_handle h, const char *key, int32_t *value)
             return SLICER_OK;
         }
     return fail(h, SLICER_ERR_ARG, "unknown option '%s'", key);
+}
+
+int slicer_libc_rand_supported(void)
+{
+    uint32_t v[31];
+    return libc_rand_grab(v) ? 1 : 0;
+}
+
+int slicer_libc_rand_state_get(uint32_t *v31)
+{
+    if (!v31)
+        return fail(nullptr, SLICER_ERR_ARG, "null argument");
+    return libc_rand_grab(v31) ? SLICER_OK : fail(nullptr, SLICER_ERR_UNSUPPORTED, "libc generator state not accessible");
+}
+
+int slicer_libc_rand_state_set(const uint32_t *v31)
+{
+    if (!v31)
+        return fail(nullptr, SLICER_ERR_ARG, "null argument");
+    return libc_rand_put(v31) ? SLICER_OK : fail(nullptr, SLICER_ERR_UNSUPPORTED, "libc generator state not accessible");
 }
 
 int slicer_set_stream(slicer_handle h, void *hip_stream)

@@ -119,12 +119,13 @@ __global__ __launch_bounds__(256) void k_direct(const float *__restrict__ pos, c
 // ---------------------------------------------------------------------------------------------
 // Shot-noise thinning (InputParams.snopt > 0, densitymaps.cpp:387-397): every selected entry, in the reference's
 // order (particle-major, then the (ni, nj) replicas), consumes one libc rand(); it keeps mass 2^snopt * m when
-// rand()/float(RAND_MAX) < 1/2^snopt and gets mass 0 otherwise.  The deviates are drawn on the host by the C ABI
-// (from the same process-global stream the reference uses), so the device needs each entry's ordinal:
+// rand()/float(RAND_MAX) < 1/2^snopt and gets mass 0 otherwise.  The deviates come from the process-global stream the
+// reference uses -- continued on the device (slicer_rand.hip) or drawn on the host by the C ABI -- as an array in
+// selection order, so the device needs each entry's ordinal:
 //   k_thin_count  : selected entries per 64-particle chunk (lane l of a chunk = particle 64*c + l)
 //   k_thin_scan   : exclusive prefix over chunks (single workgroup)
 //   k_thin_deposit: recomputes the selection, rank = base[chunk] + lanes before + replica index, then deposits
-// Two full projections per particle and global atomics: a faithful path for a rarely used option, not a fast one.
+// Two full projections per particle and global atomics for the kept entries.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lane_prefix(unsigned v, unsigned &total)
 {

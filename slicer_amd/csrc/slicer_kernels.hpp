@@ -31,12 +31,24 @@ struct LaunchCfg {
 hipError_t launch_direct(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
                          const PassParams &P, const Targets &T, hipStream_t s);
 
-// shot-noise thinning path (snopt > 0): ordered selection ranks + host-drawn libc deviates (slicer_kernels.hip)
+// shot-noise thinning path (snopt > 0): ordered selection ranks + libc deviates (slicer_kernels.hip)
 hipError_t launch_thin_count(const float *d_pos, uint64_t n, const PassParams &P, unsigned *counts,
                              unsigned long long *base, int *neg_flag, hipStream_t s);
 hipError_t launch_thin_deposit(const LaunchCfg &cfg, const float *d_pos, const float *d_mass, uint64_t n,
                                const PassParams &P, const Targets &T, const unsigned long long *base,
                                const float *urand, double thr, double mfac, hipStream_t s);
+
+// glibc's rand() stream continued on the device (slicer_rand.hip): the process-global TYPE_3 state in and out, the
+// jump tables, and the generator -- deviates [0, *d_nsel) as rand() / float(RAND_MAX), *d_nsel <= max_draws read on the
+// device; d_state (31 words, oldest first) is advanced by *d_nsel draws in place
+constexpr int kRandPow2 = 48;
+bool libc_rand_grab(uint32_t *v31);
+bool libc_rand_put(const uint32_t *v31);
+size_t rand_tables_bytes();
+hipError_t rand_tables_upload(void *d_tables, hipStream_t s);
+size_t rand_wave_states_bytes(unsigned long long max_draws);
+hipError_t launch_rand_deviates(const unsigned long long *d_nsel, uint32_t *d_state, uint32_t *d_wave_states,
+                                const void *d_tables, float *d_urand, unsigned long long max_draws, hipStream_t s);
 
 // tot = sum over types / accumulator -> f32 conversion, one plane
 struct FinalizeArgs {

@@ -719,8 +719,17 @@ def test_large_maps_8192_ngp_exact_and_16384_properties(S, sort_levels):
         del big
 
 
+@pytest.fixture(params=[0, 1], ids=["device_stream", "host_rand"])
+def thin_host(request, S):
+    """Shot-noise deviates from the device continuation of the libc stream (default) or from rand() calls on the host."""
+    S.set_option("thin_host", request.param)
+    yield request.param
+    S.plane_begin(16, 0.25, [3.0], [4.0])  # leaves any pass of the test
+    S.set_option("thin_host", 0)
+
+
 @pytest.mark.parametrize("snopt", [1, 3])
-def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
+def test_shot_noise_thinning_follows_the_libc_stream(S, snopt, thin_host):
     """InputParams.snopt > 0 (densitymaps.cpp:387-397): each selected entry draws one libc rand() in selection
     order; kept entries weigh 2^snopt m, the rest 0.  Oracle and product share this process's libc stream, so after
     srand(seed) both must consume the same deviates: NGP maps bit-exact, TSC within the usual bar, and the stream
@@ -752,6 +761,7 @@ def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
             S.file_end()
         tot, toti, cnt = S.plane_read(0)
         assert libc.rand() == after_ref            # same number of deviates consumed
+        assert (S.algo_mask() >> 3 & 1) == 1 and (S.algo_mask() >> 8 & 1) == 1 - thin_host
         assert rc == 0 and np.array_equal(cnt, nsel)
         kept = ref_toti[1].sum(dtype=np.float64) / (0.0123 * 2 ** snopt) / nsel[1]
         # about one entry in 2^snopt survives (the map misses the few per cent of entries in the border ring)
@@ -765,8 +775,41 @@ def test_shot_noise_thinning_follows_the_libc_stream(S, snopt):
             assert np.all(d <= tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2) * ref_tot)
 
 
+@pytest.mark.parametrize("nrep", [0, 1])
+def test_shot_noise_stream_on_the_device_over_many_waves(S, nrep):
+    """The device continuation of libc's rand() (slicer_rand.hip) on a chunk whose draws span several generating waves
+    (65536 deviates each) and a ragged last lane block: NGP maps bit for bit against the oracle AND against the host-rand
+    path, and the process's stream ends where the reference's would -- also with lateral replicas, where the deviate
+    buffer is sized by the real count."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    f = one_type_file(300000 if nrep else 700001)
+    npix, fov, ld, ld2, snopt = 128, 0.25 * (2 * nrep + 1), 3.0, 4.0, 2
+    libc.srand(20260917)
+    rc, ref_tot, _, nsel = oracle.create_density_maps([f], 0, 1, npix, False, True, ld, ld2, nrep, fov, RND["sgn"],
+                                                      RND["face"], RND["center"], RND["rcase"], snopt=snopt)
+    after_ref = libc.rand()
+    assert rc == 0 and nsel[1] > 4 * 65536
+    maps = []
+    for host in (0, 1):
+        S.set_option("thin_host", host)
+        libc.srand(20260917)
+        S.plane_begin(npix, fov, [ld], [ld2], [nrep], mas=slicer_amd.MAS_NGP, snopt=snopt)
+        S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        S.deposit_host(1, f["pos"])
+        S.file_end()
+        tot, _, cnt = S.plane_read(0)
+        assert libc.rand() == after_ref
+        assert (S.algo_mask() >> 8 & 1) == 1 - host
+        assert np.array_equal(cnt, nsel)
+        assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+        maps.append(tot)
+    S.set_option("thin_host", 0)
+    assert np.array_equal(maps[0], maps[1])
+
+
 @pytest.mark.parametrize("ngp", [True, False])
-def test_shot_noise_thinning_with_several_planes_in_one_pass(S, ngp):
+def test_shot_noise_thinning_with_several_planes_in_one_pass(S, ngp, thin_host):
     """The reference handles one plane per createDensityMaps call, so its rand() stream runs plane-major: all files of
     plane 0, then all files of plane 1, ...  A pass over three planes must consume the same deviates in the same order
     (the chunks are kept on the device and deposited plane by plane when the pass ends)."""
@@ -804,7 +847,7 @@ def test_shot_noise_thinning_with_several_planes_in_one_pass(S, ngp):
         S.file_end()
     assert S.algo_mask() == 0          # nothing has been deposited yet
     out = [S.plane_read(p) for p in range(3)]
-    assert S.algo_mask() & 8
+    assert S.algo_mask() & 8 and (S.algo_mask() >> 8 & 1) == 1 - thin_host
     assert libc.rand() == after_ref
     for p in range(3):
         tot, toti, cnt = out[p]
