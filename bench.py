@@ -227,6 +227,7 @@ def main():
     if rank == 0 and world == 1 and a.cpu != "off":
         cpu, ref_maps = cpu_baseline(a, want_parity)  # before anything touches the GPU in this process
     elif rank == 0 and want_parity and a.parity == "on":
+        import torch  # noqa: F401  (the worker imports slicer_amd in THIS process: torch's HIP runtime has to be first)
         _, _, ref_maps = _cpu_worker((0, a.cpu_particles, a.npix, a.mas == "ngp", a.planes, a.clustered, False, True))
 
     import torch  # first, so that libslicer_amd.so binds to the HIP runtime torch already loaded

@@ -155,6 +155,7 @@ struct K1Args {
                                // exact cell boundaries left to the exact epilogue (grid_tie, slicer_device.hpp)
     // tile geometry (BinGeom)
     int tw_log2, th_log2, ntx, tiles_per_unit, units_per_plane, rows_per_unit, n_units, nbins, batch;
+    int ntx_log2, tpu_log2;    // log2 of ntx / tiles_per_unit where both are powers of two (power-of-two maps), else -1
     // two-level sort (sort2 != 0): the kernel sorts its records by unit (= coarse bin: a band of 2^crow_log2 tile rows of
     // one plane) in LDS, sub-batch by sub-batch, and writes each sub-batch contiguously into its region of c1
     int sort2, crow_log2;

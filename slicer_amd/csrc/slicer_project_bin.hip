@@ -285,11 +285,19 @@ __device__ __forceinline__ void stage_flush(const K1Args &A, unsigned *smem, uns
 // binning + emission of one selected entry (xs, ys) of `plane`: cursor in (unit, workgroup)'s region, record, histogram
 // (s_hist / s_out / s_cnt: the workgroup's histogram, record cursors [kMaxUnits] and NGP selected-entry counters)
 // (gx, gy) = cell of (xs, ys), utilities.cpp:69-70
+// Emission variants of the fast kernel.  Every run-time flag tested per record costs the wave a scalar branch and, with
+// the kernel at its SGPR limit, `v_readlane` reloads of the spilled flag (~8 issue slots per record for the three flags
+// of the generic form): the common pass (TSC, constant mass, units = whole planes, one-level sort) has them compiled out.
+enum { kEmitGeneric = 0,  // NGP drop rule / band units / per-particle masses / staging, decided at run time
+       kEmitLean = 1,     // TSC, constant mass, units = whole planes, one-level sort
+       kEmitSort2 = 2 };  // two-level sort (staging), the rest at run time
+
+template <int MODE, bool POW2>
 __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt, bool valid,
                                             int plane, float xs, float ys, int gx, int gy, unsigned idx_in_batch,
                                             uint64_t b0, float2 *out_wg, unsigned unit_stride)
 {
-    const bool ngp = A.ngp != 0;
+    const bool ngp = MODE != kEmitLean && A.ngp != 0;
     const int nn = A.nn;
     bool emit = valid;
     if (ngp) {
@@ -302,7 +310,7 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
     // border-ring entries of TSC (g = -1 or nn) still feed the edge pixels: binned with the clamped cell
     gx = min(max(gx, 0), nn - 1);
     gy = min(max(gy, 0), nn - 1);
-    if (A.sort2) {  // two-level sort: stage the record in LDS (s_hist is the staging area here)
+    if (MODE == kEmitSort2 || (MODE == kEmitGeneric && A.sort2)) {  // two-level sort: stage the record in LDS (s_hist is the staging area here)
         const Stage St = stage_of(s_hist);
         const unsigned coarse = (unsigned)plane * (unsigned)A.units_per_plane + ((unsigned)(gy >> A.th_log2) >> A.crow_log2);
         const unsigned long long em = __ballot(emit);
@@ -325,18 +333,22 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
     if (emit) {
         const unsigned ty = (unsigned)(gy >> A.th_log2), tx = (unsigned)(gx >> A.tw_log2);
         unsigned band = 0, trow = ty;
-        if (A.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
+        if (MODE != kEmitLean && A.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
             band = ty / (unsigned)A.rows_per_unit;
             trow = ty - band * (unsigned)A.rows_per_unit;
         }
-        const unsigned unit = (unsigned)plane * (unsigned)A.units_per_plane + band;
-        const unsigned bin = unit * (unsigned)A.tiles_per_unit + trow * (unsigned)A.ntx + tx;
+        const unsigned unit = MODE == kEmitLean ? (unsigned)plane : (unsigned)plane * (unsigned)A.units_per_plane + band;
+        // (lean emission on a power-of-two map: tile counts are powers of two, the launcher checks it -- shifts
+        // instead of two quarter-rate integer multiplies)
+        const bool shifts = MODE == kEmitLean && POW2;
+        const unsigned tile_in_unit = shifts ? (trow << A.ntx_log2) | tx : trow * (unsigned)A.ntx + tx;
+        const unsigned bin = shifts ? (unit << A.tpu_log2) | tile_in_unit : unit * (unsigned)A.tiles_per_unit + tile_in_unit;
         // one returning LDS add per lane reserves the output slot in (unit, workgroup)'s region
         const unsigned o = atomicAdd(&s_out[unit], 1u);
         const unsigned idx = unit * unit_stride + o;
         out_wg[idx] = make_float2(xs, ys);
-        A.cbin[(size_t)blockIdx.x * (size_t)A.batch + idx] = (unsigned short)(trow * (unsigned)A.ntx + tx);
-        if (A.mass != nullptr)
+        A.cbin[(size_t)blockIdx.x * (size_t)A.batch + idx] = (unsigned short)tile_in_unit;
+        if (MODE != kEmitLean && A.mass != nullptr)
             A.cm[(size_t)blockIdx.x * (size_t)A.batch + idx] = A.mass[b0 + idx_in_batch];
         atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
     }
@@ -360,7 +372,7 @@ __device__ SLICER_SLOWPATH bool process_exact(const K1Kernarg *Kk, unsigned *s_h
         if (project<0>(x, y, z, 0, 0, P, xs, ys)) {
             const int gx = P.pow2 ? grid_index<true>(xs, P) : grid_index<false>(xs, P);
             const int gy = P.pow2 ? grid_index<true>(ys, P) : grid_index<false>(ys, P);
-            emit_record(A, s_hist, s_out, s_cnt, true, p, xs, ys, gx, gy, idx_in_batch, b0, out_wg, unit_stride);
+            emit_record<kEmitGeneric, false>(A, s_hist, s_out, s_cnt, true, p, xs, ys, gx, gy, idx_in_batch, b0, out_wg, unit_stride);
         }
     }
     return neg;
@@ -368,7 +380,7 @@ __device__ SLICER_SLOWPATH bool process_exact(const K1Kernarg *Kk, unsigned *s_h
 
 // Fast projection (A3) of one selected entry per lane + emission; entries it cannot decide are noted for the epilogue.
 // After the series: accept / note for the exact epilogue / emit one entry.  sn, tn: tan(dec), tan(ra); dec, ra.
-template <bool POW2>
+template <bool POW2, int MODE>
 __device__ __forceinline__ void decide_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
                                             unsigned *s_exc, unsigned *s_nexc, bool have, float ez, double sn, double tn,
                                             double dec, double ra, unsigned tag, uint64_t b0, float2 *out_wg,
@@ -398,10 +410,10 @@ __device__ __forceinline__ void decide_emit(const K1Args &A, unsigned *s_hist, u
     if (have && undecided)  // rare: noted for the exact epilogue
         s_exc[min(atomicAdd(s_nexc, 1u), kExcCap - 1)] = tag >> 3;
     const bool valid = have && !undecided && adec <= A.lim && ara <= A.lim;
-    emit_record(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, gx, gy, tag >> 3, b0, out_wg, unit_stride);
+    emit_record<MODE, POW2>(A, s_hist, s_out, s_cnt, valid, (int)(tag & 7u), xs, ys, gx, gy, tag >> 3, b0, out_wg, unit_stride);
 }
 
-template <int SERIES, bool POW2>
+template <int SERIES, bool POW2, int MODE>
 __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
                                              unsigned *s_exc, unsigned *s_nexc, bool have, float ex, float ey, float ez,
                                              unsigned tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
@@ -415,16 +427,15 @@ __device__ __forceinline__ void project_emit(const K1Args &A, unsigned *s_hist, 
     const double tn = Y * rcp_fast(Z);     // tan(ra)
     double dec, ra;
     atan_small_pair<SERIES>(sn, tn, dec, ra);
-    decide_emit<POW2>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have, ez, sn, tn, dec, ra, tag, b0, out_wg, unit_stride);
+    decide_emit<POW2, MODE>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have, ez, sn, tn, dec, ra, tag, b0, out_wg, unit_stride);
 }
 
 // Two entries per lane at once: the four arctangents share one pass over the coefficients (atan_small_quad) and give
 // the wave four independent fp64 chains.
-template <int SERIES, bool POW2>
+template <int SERIES, bool POW2, int MODE>
 __device__ __forceinline__ void project_emit2(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt,
-                                              unsigned *s_exc, unsigned *s_nexc, const bool (&have)[2],
-                                              const float (&ex)[2], const float (&ey)[2], const float (&ez)[2],
-                                              const unsigned (&tag)[2], uint64_t b0, float2 *out_wg, unsigned unit_stride)
+                                              unsigned *s_exc, unsigned *s_nexc, const bool *have, const float *ex,
+                                              const float *ey, const float *ez, const unsigned *tag, uint64_t b0, float2 *out_wg, unsigned unit_stride)
 {
     double t[4], ang[4];
 #pragma unroll
@@ -437,7 +448,7 @@ __device__ __forceinline__ void project_emit2(const K1Args &A, unsigned *s_hist,
     atan_small_quad<SERIES>(t, ang);
 #pragma unroll
     for (int j = 0; j < 2; j++)
-        decide_emit<POW2>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have[j], ez[j], t[2 * j], t[2 * j + 1], ang[2 * j],
+        decide_emit<POW2, MODE>(A, s_hist, s_out, s_cnt, s_exc, s_nexc, have[j], ez[j], t[2 * j], t[2 * j + 1], ang[2 * j],
                           ang[2 * j + 1], tag[j], b0, out_wg, unit_stride);
 }
 
@@ -447,9 +458,10 @@ __device__ __forceinline__ void project_emit2(const K1Args &A, unsigned *s_hist,
 // write -> read round trips of the stack cost more than the idle lanes).
 // SORT2: the two-level sort (staging in LDS, sub-batches sorted by unit; see Stage) instead of per-record scatter + tile
 // histogram.  Not combined with STACK (the wave stacks and the staging area do not both fit twice per CU).
-template <int FACE, int SERIES, bool STACK, bool POW2, bool SORT2>
+template <int FACE, int SERIES, bool STACK, bool POW2, int MODE>
 __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_bin_fast(K1Kernarg K)
 {
+    constexpr bool SORT2 = MODE == kEmitSort2;
     static_assert(!(STACK && SORT2), "the two-level sort runs without the wave stacks");
     const K1Args &A = K.A;  // K.P is read through the kernarg segment by the exact epilogue only
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
     unsigned top = 0;  // entries on this wave's stack (wave-uniform)
 
     const uint64_t w0 = b0 + (uint64_t)wave * (64 * kPerThread);
-    RawRound cur, nxt;
+    RawRound cur;
     const __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(A.pos, b0, b1);
     uint64_t i0 = w0 + (uint64_t)kPerThread * lane;
     int nvalid = i0 < b1 ? (int)dmin<uint64_t>(kPerThread, b1 - i0) : 0;
@@ -507,18 +519,15 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
         const uint64_t i1 = i0 + kRound;
         const bool more = r0 + kRound < lim;
         const int nvalid1 = (more && i1 < b1) ? (int)dmin<uint64_t>(kPerThread, b1 - i1) : 0;
-        load_round(rsrc, (unsigned)(i1 - b0), nxt);  // (beyond the batch: zeros, no memory access)
 
-        // ---- transform, slab select, conservative FOV pre-test; push (STACK) or project two particles at a time ----
+        // ---- transform, slab select, conservative FOV pre-test of the round's particles; push (STACK) ----
         static_assert(kPerThread % 2 == 0, "particles are projected in pairs");
+        float px[kPerThread], py[kPerThread], pz[kPerThread];
+        bool psel[kPerThread];
+        unsigned ptag[kPerThread];
+        {
 #pragma unroll
-        for (int k0 = 0; k0 < kPerThread; k0 += 2) {
-            float px[2], py[2], pz[2];
-            bool psel[2];
-            unsigned ptag[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int k = k0 + j;
+            for (int k = 0; k < kPerThread; k++) {
                 // face permutation (gadget2io.cpp:222-252): output axis a reads source axis perm[a]
                 constexpr int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}};
                 const float src[3] = {cur.v[3 * k], cur.v[3 * k + 1], cur.v[3 * k + 2]};
@@ -568,11 +577,20 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                     }
                     top += (unsigned)__popcll(mask);
                 }
-                px[j] = x, py[j] = y, pz[j] = z, psel[j] = sel, ptag[j] = tag;
+                px[k] = x, py[k] = y, pz[k] = z, psel[k] = sel, ptag[k] = tag;
             }
-            if (!STACK && __ballot(psel[0] || psel[1]) != 0ull)
-                project_emit2<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, psel, px, py, pz, ptag, b0, out_wg,
-                                            unit_stride);
+        }
+        // The raw positions are dead from here on: the next round's are requested INTO THE SAME VARIABLE (beyond the
+        // batch: zeros, no memory access) and have the projection + emission below, four fifths of the round, to
+        // arrive.  (Loading into a second buffer at the top of the round cost twelve register copies per round at the
+        // bottom of it.)
+        load_round(rsrc, (unsigned)(i1 - b0), cur);
+        if (!STACK) {  // ---- fp64 projection + emission in place, two particles at a time ----
+#pragma unroll
+            for (int k0 = 0; k0 < kPerThread; k0 += 2)
+                if (__ballot(psel[k0] || psel[k0 + 1]) != 0ull)
+                    project_emit2<SERIES, POW2, MODE>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, psel + k0, px + k0, py + k0,
+                                                      pz + k0, ptag + k0, b0, out_wg, unit_stride);
         }
         if (STACK) {
             lds_fence();
@@ -584,7 +602,7 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
                 if (have)
                     ent = q4[top - take + lane];
                 top -= take;
-                project_emit<SERIES, POW2>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, have, ent.x, ent.y, ent.z,
+                project_emit<SERIES, POW2, MODE>(A, s_hist, s_out, s_cnt, s_exc, &s_nexc, have, ent.x, ent.y, ent.z,
                                      __float_as_uint(ent.w), b0, out_wg, unit_stride);
             }
             lds_fence();
@@ -595,11 +613,10 @@ __global__ __launch_bounds__(kK1Block, SLICER_K1_WAVES_PER_SIMD) void k_project_
             // for the stores to be acknowledged (~1-2 us per flush on the critical path).
 #pragma unroll
             for (int k = 0; k < 3 * kPerThread; k++)
-                asm volatile("" : "+v"(nxt.v[k]));
+                asm volatile("" : "+v"(cur.v[k]));
             stage_flush(A, smem, (unsigned)(kStageCap - kRound), st_off, st_slot);
         }
 
-        cur = nxt;
         i0 = i1;
         nvalid = nvalid1;
     }
@@ -946,12 +963,23 @@ static hipError_t launch_k1_fast(bool s9, int nb, size_t lds, const PassParams &
         else                                                                          \
             K1F_(S_, ST_, false, S2_);                                                \
     } while (0)
+    // the lean emission where no run-time variant of it is needed (emit_record)
+    const bool lean = !A.sort2 && !A.ngp && A.units_per_plane == 1 && A.mass == nullptr &&
+                      (!A.pow2 || (A.ntx_log2 >= 0 && A.tpu_log2 >= 0));
     if (A.sort2) {  // (never with the wave stacks: the host clears `stack` when it picks the two-level sort)
-        if (s9) K1F(9, false, true); else K1F(15, false, true);
+        if (s9) K1F(9, false, kEmitSort2); else K1F(15, false, kEmitSort2);
     } else if (A.stack) {
-        if (s9) K1F(9, true, false); else K1F(15, true, false);
+        if (lean) {
+            if (s9) K1F(9, true, kEmitLean); else K1F(15, true, kEmitLean);
+        } else {
+            if (s9) K1F(9, true, kEmitGeneric); else K1F(15, true, kEmitGeneric);
+        }
     } else {
-        if (s9) K1F(9, false, false); else K1F(15, false, false);
+        if (lean) {
+            if (s9) K1F(9, false, kEmitLean); else K1F(15, false, kEmitLean);
+        } else {
+            if (s9) K1F(9, false, kEmitGeneric); else K1F(15, false, kEmitGeneric);
+        }
     }
 #undef K1F_
 #undef K1F
@@ -1002,6 +1030,13 @@ hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_po
         A.neg_flag = T.neg_flag;
         A.nsel = T.nsel[0];
         A.tw_log2 = G.tw_log2, A.th_log2 = G.th_log2, A.ntx = G.ntx, A.tiles_per_unit = G.tiles_per_unit;
+        auto log2_exact = [](int v) {
+            int l = 0;
+            while ((1 << l) < v)
+                l++;
+            return (1 << l) == v ? l : -1;
+        };
+        A.ntx_log2 = log2_exact(G.ntx), A.tpu_log2 = log2_exact(G.tiles_per_unit);
         A.units_per_plane = G.units_per_plane, A.rows_per_unit = G.rows_per_unit, A.n_units = G.n_units;
         A.nbins = G.nbins, A.batch = G.batch;
         A.c1 = W.c1;
