@@ -853,7 +853,7 @@ __device__ __forceinline__ void tile_accumulate_chunks(const PendingList &L, con
 struct RunRef {
     unsigned chunk, start;  // records [start, start + length) of L.sxy[chunk]; length = s_pre[k + 1] - s_pre[k]
 };
-constexpr int kMaxRuns = kMaxPending * kMaxSortGroups;
+constexpr int kMaxRuns = kMaxPendingRuns * kMaxSortGroups;
 constexpr unsigned kWalkWindow = 65536;  // records walked per s_first table (kWalkWindow / 64 entries)
 
 struct RunTable {
@@ -1632,19 +1632,19 @@ hipError_t launch_sort2(int nblocks, int slots_per_group, int ngroups, int max_w
     return hipGetLastError();
 }
 
-size_t tile_lds_bytes(const BinGeom &G, int acc)
+size_t tile_lds_bytes(const BinGeom &G, int acc, bool runs)
 {
     const size_t elem = acc == kCountU32 ? 4 : 8;
     const size_t cells = (size_t)((1 << G.tw_log2) + 2) * (size_t)((1 << G.th_log2) + 2);
     return ((elem * cells + 7) & ~(size_t)7) + 8 + ((acc == kF32I || acc == kF64I) ? kSlowCap * sizeof(uint2) : 0) +
-           kRunTableBytes;
+           (runs ? kRunTableBytes : 0);  // (the run table of the two-level sort's walk)
 }
 
 template <int MAS, int ACC>
 static hipError_t launch_k4(bool pow2, bool has_mass, const PassParams &P, const BinGeom &G, const PendingList &L,
                             const Targets &T, const TileItems &I, const NgpFold &F, unsigned max_items, hipStream_t s)
 {
-    const size_t lds = tile_lds_bytes(G, ACC);
+    const size_t lds = tile_lds_bytes(G, ACC, L.tot != nullptr);
 #define K4_(P2_, HM_, RN_)                                                                                       \
     do {                                                                                                         \
         auto kern = k_tile_deposit<MAS, ACC, P2_, HM_, RN_>;                                                     \

@@ -56,6 +56,7 @@ struct Options {
     int k1_stack = -1;    // fast project+bin kernel: compact survivors through the wave stack (0 / 1; -1 = by slab depth)
     int ngp_general = 0;  // 1: no in-tile NGP fold (count map + k_fold_ngp)
     int dl_quot = 1;      // maps that are not a power of two wide: allow the swept reciprocal-product quotient
+    int pending = 0;      // chunks per tile launch (0 = automatic: 8 ... 32 by the records a chunk brings per tile)
     int thin_host = 0;    // 1: shot-noise deviates drawn by libc rand() on the host (0: the stream continues on the device)
     int sort2 = 0;        // 1: two-level sort (project+bin sorts by coarse bin in LDS, k_sort2 by tile) where a pass
                           // qualifies.  Off by default: it moves fewer bytes but costs more instructions
@@ -77,6 +78,7 @@ const OptionName kOptionNames[] = {
     {"dl_quot", "SLICER_DL_QUOT", &Options::dl_quot},
     {"sort2", "SLICER_SORT2", &Options::sort2},
     {"thin_host", "SLICER_THIN_HOST", &Options::thin_host},
+    {"pending", "SLICER_PENDING", &Options::pending},
 };
 
 struct slicer_handle_s {
@@ -165,6 +167,7 @@ struct slicer_handle_s {
         // two-level sort: the chunk's item table (w_base then holds the items' allocation cursor), the group's bin totals
         DevBuf w_ptab[kMaxPending], w_tot;
         bool sort2 = false;
+        int limit = 8;  // chunks per tile launch of this list (set when its first chunk arrives)
     };
     Pending pg[SLICER_MAX_PLANES];
 
@@ -1083,7 +1086,7 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
         A.sort2 = 1;
         A.crow_log2 = crow_log2;
     }
-    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n == kMaxPending || Q.sort2 != sort2) &&
+    if (Q.L.n && (Q.key != key || Q.p0 != p0 || Q.np != np || Q.L.n >= Q.limit || Q.sort2 != sort2) &&
         (rc = flush_group(h, group)))
         return rc;
     const int slot = Q.L.n;
@@ -1123,6 +1126,13 @@ int binned_chunk(slicer_handle h, const LaunchCfg &cfg, const PassParams &P, con
         Q.L.ngroups[slot] = 1;
     }
     if (slot == 0) {
+        // chunks per tile launch: enough for ~16384 records per bin (what eight chunks of the headline case bring),
+        // judged by the first chunk; option `pending` overrides
+        const uint64_t per_bin = std::max<uint64_t>(1, n * (uint64_t)(G.region / G.batch) / (uint64_t)std::max(1, G.nbins));
+        int limit = (int)std::min<uint64_t>(kMaxPending, std::max<uint64_t>(8, (16384 + per_bin - 1) / per_bin));
+        if (h->opt.pending > 0)
+            limit = std::min(h->opt.pending, kMaxPending);
+        Q.limit = sort2 ? std::min(limit, kMaxPendingRuns) : limit;
         Q.key = key;
         Q.sort2 = sort2;
         Q.p0 = p0;

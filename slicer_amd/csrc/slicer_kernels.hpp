@@ -181,7 +181,7 @@ hipError_t launch_check_box_quotient(double box, unsigned *d_mismatches, hipStre
 
 size_t project_bin_lds_bytes(const BinGeom &G, bool has_mass);
 size_t project_bin_sort2_lds_bytes();
-size_t tile_lds_bytes(const BinGeom &G, int acc);
+size_t tile_lds_bytes(const BinGeom &G, int acc, bool runs);
 size_t scatter_lds_bytes(const BinGeom &G, bool has_mass);
 hipError_t launch_project_bin(const LaunchCfg &cfg, bool fast, const float *d_pos, const float *d_mass, uint64_t n,
                               const PassParams &P, const K1Args &A, const BinGeom &G, const BinWorkspace &W,
@@ -197,10 +197,14 @@ hipError_t launch_sort2(int nblocks, int slots_per_group, int ngroups, int max_w
                         const BinGeom &G, const BinWorkspace &W, hipStream_t s);
 // Chunks whose records are binned but not yet deposited: the tile kernel walks all of them, so one
 // LDS tile zero + flush is amortised over up to kMaxPending chunks (e.g. the sub-files of a snapshot).
+// The host flushes at pending_limit() chunks: 8 where a chunk brings a tile ~2048 records (the headline case: more per
+// launch measured no better), up to kMaxPending where a chunk brings few (16384^2 maps: zeroing and flushing a 68 KB
+// tile for ~500 records is most of the kernel); the two-level sort's run table holds kMaxPendingRuns chunks.
 #ifndef SLICER_MAX_PENDING
-#define SLICER_MAX_PENDING 8
+#define SLICER_MAX_PENDING 32
 #endif
 constexpr int kMaxPending = SLICER_MAX_PENDING;
+constexpr int kMaxPendingRuns = 8;
 constexpr int kMaxSortGroups = 32;  // two-level sort: items (groups of project+bin workgroups) per coarse bin and chunk
 struct PendingList {
     int n;

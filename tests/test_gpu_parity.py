@@ -926,6 +926,31 @@ def test_explicit_binned_request_fails_loudly_when_unsupported(S):
     assert np.array_equal(cnt, nsel) and np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
 
 
+@pytest.mark.parametrize("ngp", [True, False])
+def test_up_to_32_chunks_wait_for_one_tile_launch(S, ngp):
+    """The pending list holds up to 32 binned chunks (8 where a chunk brings a tile ~2048 records, more where it brings
+    few: large maps); here 20 sub-files of one species go through ONE tile-kernel launch (option pending = 32), and
+    through launches of 8 + 8 + 4 (pending = 8): NGP bit for bit like the oracle -- including the in-tile per-file fold
+    over 20 files -- TSC within the usual bar, both ways."""
+    files, first = [], 0
+    for ff in range(20):
+        files.append(one_type_file(20000 + 7 * ff, first=first))
+        first += 20000 + 7 * ff
+    npix = 256
+    ref_tot, _, nsel = run_oracle(files, npix, 0.25, 3.0, 4.0, ngp=ngp)
+    for limit in (32, 8):
+        S.set_option("pending", limit)
+        (tot, _, cnt), = run_gpu(S, files, npix, 0.25, [3.0], [4.0], ngp=ngp, algo=slicer_amd.ALGO_BINNED)
+        assert np.array_equal(cnt, nsel)
+        if ngp:
+            assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+        else:
+            nz = ref_tot > 0
+            assert float((np.abs(tot[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max()) < tsc_gate(
+                1.5 * 9 * nsel.sum() / npix ** 2)
+    S.set_option("pending", 0)
+
+
 @pytest.mark.parametrize("nrep,ngp", [(4, True), (5, False), (8, True)])
 def test_many_lateral_replications_run_binned_in_replica_windows(S, nrep, ngp):
     """VERDICT r2 missing 4: more than three lateral replications per side ((2n+1)^2 = 81 ... 289 replicas per particle,
