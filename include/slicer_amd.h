@@ -159,6 +159,14 @@ int slicer_libc_rand_supported(void);
  * rand() = x[n] >> 1): read, and install.  Test hooks of the above; SLICER_ERR_UNSUPPORTED if not supported. */
 int slicer_libc_rand_state_get(uint32_t *v31);
 int slicer_libc_rand_state_set(const uint32_t *v31);
+/* A stream of the handle's own for the shot-noise deviates, in the same 31-word form, instead of the process-global
+ * one: the reference's MPI ranks each own an identically seeded copy of libc's stream and consume it independently
+ * (densitymaps.cpp:187-217 seeds it in every rank alike); threads of ONE process that drive one device each get the same
+ * by reading the process state once after the plan is made (slicer_libc_rand_state_get) and handing every handle a copy.
+ * The handle's state advances with its draws (slicer_rand_stream_get reads it back); libc's own stream is not touched.
+ * v31 = NULL returns the handle to the process-global stream.  Not inside a file. */
+int slicer_rand_stream_set(slicer_handle h, const uint32_t *v31);
+int slicer_rand_stream_get(slicer_handle h, uint32_t *v31);
 
 /* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = handle-owned. */
 int slicer_set_stream(slicer_handle h, void *hip_stream);

@@ -45,6 +45,8 @@ SYMBOLS = {
     "slicer_libc_rand_supported": (C.c_int, []),
     "slicer_libc_rand_state_get": (C.c_int, [C.POINTER(C.c_uint32)]),
     "slicer_libc_rand_state_set": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "slicer_rand_stream_set": (C.c_int, [_H, C.POINTER(C.c_uint32)]),
+    "slicer_rand_stream_get": (C.c_int, [_H, C.POINTER(C.c_uint32)]),
     "slicer_set_stream": (C.c_int, [_H, C.c_void_p]),
     "slicer_plane_begin": (C.c_int, [_H, C.POINTER(PlaneDesc)]),
     "slicer_file_begin": (C.c_int, [_H, C.POINTER(FileDesc)]),

@@ -215,6 +215,19 @@ class Slicer:
         self._chk(_L.slicer_plane_device_guard(self._h, C.byref(p)))
         return p.value
 
+    def rand_stream_set(self, v31):
+        """Shot-noise deviates from a stream of this handle's own (31 words, oldest first; None: back to the process-global
+        libc stream) -- include/slicer_amd.h: slicer_rand_stream_set."""
+        if v31 is None:
+            self._chk(_L.slicer_rand_stream_set(self._h, None))
+        else:
+            self._chk(_L.slicer_rand_stream_set(self._h, (C.c_uint32 * 31)(*[int(x) for x in v31])))
+
+    def rand_stream_get(self):
+        v = (C.c_uint32 * 31)()
+        self._chk(_L.slicer_rand_stream_get(self._h, v))
+        return list(v)
+
     def get_stream(self):
         p = C.c_void_p()
         self._chk(_L.slicer_get_stream(self._h, C.byref(p)))

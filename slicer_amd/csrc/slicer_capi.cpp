@@ -138,6 +138,10 @@ struct slicer_handle_s {
     DevBuf w_randtab, w_randstate, w_randwaves;
     bool rand_tab_ready = false;
     bool rand_on_device = false;  // between thin_rng_begin and thin_rng_end the device holds the stream
+    // a stream of this handle's own instead of the process-global one (slicer_rand_stream_set): the reference's MPI
+    // ranks each own an identically seeded copy of libc's stream; rank threads of one process get theirs this way
+    bool rand_private = false;
+    uint32_t rand_state[31] = {};
     // snopt > 0 with several planes in one pass: the reference draws its deviates plane by plane (outer loop of
     // createDensityMaps' caller), so the chunks are kept on the device and deposited plane-major when the pass ends
     struct ThinChunk {
@@ -875,7 +879,9 @@ bool thin_rng_begin(slicer_handle h, int &rc)
     if (h->opt.thin_host)
         return false;
     uint32_t v[31];
-    if (!libc_rand_grab(v))
+    if (h->rand_private)
+        memcpy(v, h->rand_state, sizeof v);
+    else if (!libc_rand_grab(v))
         return false;
     if ((rc = ensure(h, h->w_randtab, rand_tables_bytes())) || (rc = ensure(h, h->w_randstate, 32 * 4)))
         return false;
@@ -903,7 +909,9 @@ int thin_rng_end(slicer_handle h)
     uint32_t v[31];
     HIPCHK(h, hipMemcpyAsync(v, h->w_randstate.p, sizeof v, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (!libc_rand_put(v))
+    if (h->rand_private)
+        memcpy(h->rand_state, v, sizeof v);
+    else if (!libc_rand_put(v))
         return fail(h, SLICER_ERR_STATE, "the process changed its libc generator during a thinned pass");
     return SLICER_OK;
 }
@@ -950,8 +958,11 @@ int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg 
     HIPCHK(h, hipMemcpyAsync(&nsel, d_nsel, sizeof nsel, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->h_urand.resize(nsel);
-    for (unsigned long long k = 0; k < nsel; k++)
-        h->h_urand[k] = rand() / float(RAND_MAX);
+    if (h->rand_private)
+        libc_rand_model_fill(h->rand_state, h->h_urand.data(), nsel);
+    else
+        for (unsigned long long k = 0; k < nsel; k++)
+            h->h_urand[k] = rand() / float(RAND_MAX);
     if ((rc = ensure(h, h->w_urand, std::max<size_t>(nsel, 1) * 4)))
         return rc;
     if (nsel)
@@ -1474,6 +1485,28 @@ int slicer_get_option(slicer_handle h, const char *key, int32_t *value)
             return SLICER_OK;
         }
     return fail(h, SLICER_ERR_ARG, "unknown option '%s'", key);
+}
+
+int slicer_rand_stream_set(slicer_handle h, const uint32_t *v31)
+{
+    if (!h)
+        return fail(h, SLICER_ERR_ARG, "null handle");
+    if (h->in_file)
+        return fail(h, SLICER_ERR_STATE, "slicer_rand_stream_set inside a file");
+    h->rand_private = v31 != nullptr;
+    if (v31)
+        memcpy(h->rand_state, v31, sizeof h->rand_state);
+    return SLICER_OK;
+}
+
+int slicer_rand_stream_get(slicer_handle h, uint32_t *v31)
+{
+    if (!h || !v31)
+        return fail(h, SLICER_ERR_ARG, "null argument");
+    if (!h->rand_private)
+        return fail(h, SLICER_ERR_STATE, "the handle draws from the process-global stream (slicer_rand_stream_set)");
+    memcpy(v31, h->rand_state, sizeof h->rand_state);
+    return SLICER_OK;
 }
 
 int slicer_libc_rand_supported(void)

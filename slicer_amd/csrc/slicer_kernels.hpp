@@ -44,6 +44,7 @@ hipError_t launch_thin_deposit(const LaunchCfg &cfg, const float *d_pos, const f
 constexpr int kRandPow2 = 48;
 bool libc_rand_grab(uint32_t *v31);
 bool libc_rand_put(const uint32_t *v31);
+void libc_rand_model_fill(uint32_t *v31, float *out, unsigned long long n);
 size_t rand_tables_bytes();
 hipError_t rand_tables_upload(void *d_tables, hipStream_t s);
 size_t rand_wave_states_bytes(unsigned long long max_draws);

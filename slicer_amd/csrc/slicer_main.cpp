@@ -10,7 +10,8 @@
 //     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
 //   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
 //     partinplanes runs write their per-type files;                                      --reference-counts disables
-//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass and one device
+//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass; with several
+//     devices every rank thread then draws from its own copy of the libc stream, like the reference's MPI ranks
 //     (the thinning deviates come from the process-global libc rand() stream, densitymaps.cpp:387-397: the reference's
 //     MPI ranks each own an identically seeded copy of it, host threads of one process would interleave their draws).
 #include <dlfcn.h>
@@ -361,11 +362,17 @@ int main(int argc, char **argv)
         cerr << "bad --devices / --reduce / --reduce-algo" << endl;
         return 2;
     }
-    if (p.snopt != 0 && devs.size() > 1) {
-        cerr << "snopt > 0 needs a single device: the shot-noise thinning draws from the process-global libc rand() "
-                "stream in selection order (densitymaps.cpp:387-397); the reference's MPI ranks each own an identically "
-                "seeded copy of that stream, the rank threads of this process would interleave their draws and no two "
-                "runs would agree" << endl;
+    // snopt > 0 with several devices: the reference's MPI ranks each own an identically seeded copy of libc's rand()
+    // stream (randomizeBox seeds it in every rank alike) and consume it independently (densitymaps.cpp:387-397).  The
+    // rank threads of this process would interleave their draws on the one process-global stream, so every rank's
+    // handle gets a stream of its own, started from the process state as randomizeBox left it -- the run then equals a
+    // reference run on as many MPI ranks.  Where that state cannot be read (no glibc TYPE_3 generator) the combination
+    // stays refused.
+    uint32_t rank_stream[31];
+    const bool private_streams = p.snopt != 0 && devs.size() > 1;
+    if (private_streams && slicer_libc_rand_state_get(rank_stream) != SLICER_OK) {
+        cerr << "snopt > 0 on several devices needs per-rank copies of the libc rand() stream, which this C library does "
+                "not expose (slicer_libc_rand_supported() == 0): use a single device" << endl;
         return 2;
     }
     const int rccl_algo = reduce_algo == "direct" ? SLICER_RCCL_REDUCE_DIRECT : SLICER_RCCL_REDUCE_ROOTED;
@@ -374,6 +381,10 @@ int main(int argc, char **argv)
         ranks[r].device = devs[r];
         if (slicer_create(devs[r], 1ull << 24, &ranks[r].h) != SLICER_OK) {
             cerr << "slicer_amd: " << slicer_last_error(nullptr) << endl;
+            return 1;
+        }
+        if (private_streams && slicer_rand_stream_set(ranks[r].h, rank_stream) != SLICER_OK) {
+            cerr << "slicer_amd: " << slicer_last_error(ranks[r].h) << endl;
             return 1;
         }
     }

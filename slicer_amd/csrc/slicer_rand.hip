@@ -197,6 +197,14 @@ bool libc_rand_put(const uint32_t *v31)
     return ok;
 }
 
+// n draws of the model recurrence on the host (a handle-private stream without the device path): out[k] as
+// rand() / float(RAND_MAX); v31 is advanced
+void libc_rand_model_fill(uint32_t *v31, float *out, unsigned long long n)
+{
+    for (unsigned long long k = 0; k < n; k++)
+        out[k] = (float)(int)model_draw(v31) / float(RAND_MAX);
+}
+
 size_t rand_tables_bytes() { return ((size_t)kRandPow2 * kDeg * kDeg + (size_t)kDeg * kDeg * 64) * sizeof(uint32_t); }
 
 hipError_t rand_tables_upload(void *d_tables, hipStream_t s)

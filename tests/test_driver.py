@@ -209,12 +209,28 @@ def test_a_rank_that_fails_locally_stops_every_rank_before_the_collective(tmp_pa
     assert not [f for f in os.listdir(out) if f.endswith(".fits")]
 
 
-def test_shot_noise_thinning_refuses_several_devices(tmp_path):
-    """snopt > 0 draws from the process-global libc rand() stream (densitymaps.cpp:387-397): rank threads of one process
-    would interleave their draws, so the driver refuses instead of writing maps that differ from run to run."""
-    ini, _, _ = make_cone(tmp_path, snopt=2)
-    r = run([ini, "--devices", "0,0", "--reduce", "host"])
-    assert r.returncode == 2 and "snopt > 0 needs a single device" in r.stderr
+@pytest.mark.gpu
+def test_shot_noise_thinning_on_several_devices_is_reproducible(tmp_path):
+    """snopt > 0 draws from libc's rand() stream (densitymaps.cpp:387-397).  The reference's MPI ranks each own an
+    identically seeded copy of it; the rank threads of this process each get one as well (slicer_rand_stream_set, started
+    from the process state randomizeBox left), instead of interleaving their draws on the process-global stream (ADVICE
+    r2; the combination used to be refused): two runs write identical files, and they differ from the one-rank run only
+    where the thinning differs -- the selected counts in the headers agree."""
+    ini, _, out = make_cone(tmp_path, snopt=2)
+    runs = []
+    for k in range(2):
+        r = run([ini, "--ngp", "--devices", "0,0", "--reduce", "host"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append({f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out)) if f.endswith(".fits")})
+        for f in runs[-1]:
+            os.remove(os.path.join(out, f))
+    assert len(runs[0]) >= 10 and runs[0].keys() == runs[1].keys()
+    for f in runs[0]:
+        assert runs[0][f] == runs[1][f], f
+    assert run([ini, "--ngp"]).returncode == 0
+    for f in runs[0]:
+        one = open(os.path.join(out, f), "rb").read()
+        assert one[:2880] == runs[0][f][:2880], f   # same header: same selected counts (NPARTTYPE*), same plane
     assert run([ini, "--plan-only", "--devices", "0,0"]).returncode == 0
 
 

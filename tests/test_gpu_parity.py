@@ -30,7 +30,7 @@ U24 = 2.0 ** -24
 
 
 OPTION_KEYS = ("k4_int", "tile_log2", "tile_h_log2", "bin_batch", "unit_rows", "k3_per_cu", "k1_general", "k1_stack",
-               "ngp_general", "dl_quot", "sort2")
+               "ngp_general", "dl_quot", "sort2", "pending", "thin_host")
 
 
 @pytest.fixture(scope="module")
@@ -806,6 +806,81 @@ def test_shot_noise_stream_on_the_device_over_many_waves(S, nrep):
         maps.append(tot)
     S.set_option("thin_host", 0)
     assert np.array_equal(maps[0], maps[1])
+
+
+@pytest.mark.parametrize("host", [0, 1], ids=["device_stream", "host_model"])
+def test_shot_noise_with_a_stream_per_handle_equals_a_run_on_as_many_ranks(S0, host):
+    """The reference's MPI ranks each own an identically seeded copy of libc's rand() stream and consume it independently,
+    plane after plane (densitymaps.cpp:187-217, 387-397).  Two handles with streams of their own
+    (slicer_rand_stream_set), each depositing its range of sub-files, give what two reference ranks give -- emulated here
+    by switching libc's state between the oracle's "ranks" -- and leave the process's own stream untouched."""
+    import ctypes as C
+    from slicer_amd import _lib
+    libc = C.CDLL("libc.so.6")
+    L = _lib.load()
+    files, first = [], 0
+    for ff in range(4):
+        files.append(one_type_file(30001 + 11 * ff, first=first))
+        first += 30001 + 11 * ff
+    ranges = [(0, 2), (2, 4)]
+    npix, fov, snopt = 64, 0.25, 2
+    lds = [3.0, 3.5, 4.0]
+    libc.srand(31337)
+    for _ in range(9):
+        libc.rand()           # (as if randomizeBox had drawn a few)
+    s0 = (C.c_uint32 * 31)()
+    assert L.slicer_libc_rand_state_get(s0) == 0
+    start = list(s0)
+    # the reference on two ranks: each rank's stream lives on from plane to plane
+    state = [list(start), list(start)]
+    ref = []
+    for p in range(2):
+        tot = np.zeros((npix, npix), np.float32)
+        cnt = np.zeros(6, np.int64)
+        for r, (lo, hi) in enumerate(ranges):
+            assert L.slicer_libc_rand_state_set((C.c_uint32 * 31)(*state[r])) == 0
+            rc, t, _, nsel = oracle.create_density_maps(files, lo, hi, npix, False, True, lds[p], lds[p + 1], 0, fov,
+                                                        RND["sgn"], RND["face"], RND["center"], RND["rcase"], snopt=snopt)
+            assert rc == 0
+            g = (C.c_uint32 * 31)()
+            assert L.slicer_libc_rand_state_get(g) == 0
+            state[r] = list(g)
+            tot = tot + t      # MPI_Reduce(SUM) of two f32 maps
+            cnt += nsel
+        ref.append((tot, cnt))
+    assert state[0] != state[1]
+    # the product: one handle per rank
+    assert L.slicer_libc_rand_state_set((C.c_uint32 * 31)(*start)) == 0
+    marker = [libc.rand() for _ in range(3)]
+    assert L.slicer_libc_rand_state_set((C.c_uint32 * 31)(*start)) == 0
+    handles = [S0, slicer_amd.Slicer(0)]
+    try:
+        for h in handles:
+            h.set_option("thin_host", host)
+            h.rand_stream_set(start)
+        for p in range(2):
+            tot = np.zeros((npix, npix), np.float32)
+            cnt = np.zeros(6, np.int64)
+            for h, (lo, hi) in zip(handles, ranges):
+                h.plane_begin(npix, fov, [lds[p]], [lds[p + 1]], mas=slicer_amd.MAS_NGP, snopt=snopt)
+                for f in files[lo:hi]:
+                    h.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+                    h.deposit_host(1, f["pos"])
+                    h.file_end()
+                t, _, c = h.plane_read(0)
+                assert (h.algo_mask() >> 8 & 1) == 1 - host
+                tot = tot + t
+                cnt += c
+            assert np.array_equal(cnt, ref[p][1]) and cnt[1] > 0
+            assert np.array_equal(tot.view(np.uint32), ref[p][0].view(np.uint32))
+        assert [handles[r].rand_stream_get() for r in range(2)] == state
+        assert [libc.rand() for _ in range(3)] == marker      # the process's own stream: not consumed
+    finally:
+        for h in handles:
+            h.plane_begin(16, 0.25, [3.0], [4.0])
+            h.set_option("thin_host", 0)
+            h.rand_stream_set(None)
+        handles[1].close()
 
 
 @pytest.mark.parametrize("ngp", [True, False])
