@@ -63,13 +63,18 @@ def parse():
     ap.add_argument("--hydro", action="store_true",
                     help="per-particle masses (type 0, massarr = 0: densitymaps.cpp:358-372) instead of one mass per type")
     ap.add_argument("--shard", default="auto", choices=["auto", "snapshots", "files", "steps"],
-                    help="auto: steps (strong scaling, whole steps per rank, finished maps sent to rank 0) when N > 1")
+                    help="auto: steps (strong scaling: step i is built by rank i % N, whole) when N > 1")
     ap.add_argument("--streams", type=int, default=1,
                     help="snapshots in flight per GPU: consecutive steps alternate between this many handles, each on "
                          "its own HIP stream.  With more than one the job is timed on ONE stream first (`single_stream`; "
                          "the per-kernel durations of `roofline` / `kernels` belong to that run) and `value` is the "
                          "multi-stream run.  Measured gain of 2 over 1: about 2 %, inside the run-to-run scatter "
                          "(DESIGN.md S5), hence the default of 1")
+    ap.add_argument("--gather", default="off", choices=["on", "off"],
+                    help="--shard steps: also send every finished map to rank 0 (point to point, overlapped).  Off: the maps "
+                         "stay on the rank that built them, as for N = 1 (snapshots and lens planes are independent: each "
+                         "rank would write its own planes); the gathering variant is timed in the same run as "
+                         "config.reduce_layout.steps_gather")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--reduce-algo", default="rooted", choices=["rooted", "rs_gather", "p2p"],
                     help="--shard files: the per-plane rank sum as one library reduce per map (rooted), as reduce-scatter "
@@ -300,12 +305,13 @@ def main():
     class Layout:
         """One way of spreading the job over the ranks: its handles, its step function, its timed run."""
 
-        def __init__(self, shard, reduce_algo="rooted", streams=None):
+        def __init__(self, shard, reduce_algo="rooted", streams=None, gather=None):
             self.shard, self.reduce_algo = shard, reduce_algo
             streams = a.streams if streams is None else streams
             self.reduce_steps = shard == "files" and use_dist
-            self.gather_steps = shard == "steps" and use_dist
-            self.overlap = (self.reduce_steps or self.gather_steps) and not a.no_overlap
+            self.gather_steps = shard == "steps" and use_dist  # whole steps per rank (step i: rank i % N)
+            self.gather = self.gather_steps and (a.gather == "on" if gather is None else gather)  # ... maps to rank 0
+            self.overlap = (self.reduce_steps or self.gather) and not a.no_overlap
             # Two handles when the rank sum of step i overlaps the deposits of step i+1: each owns its maps and
             # workspace and works on its own stream; RCCL runs on torch.distributed's communication stream.
             self.n_handles = max(2 if self.overlap else 1, streams)
@@ -321,7 +327,7 @@ def main():
                 self.my_files = list(range(files))
             self.pending = [None] * self.n_handles  # async rank-sum / send works of the handle's previous step
             self.G = None
-            if self.gather_steps:
+            if self.gather:
                 self.G = parallel.StepGather(dist, torch, world, rank, len(lds), npix2, torch.float32, "cuda", root=0,
                                              depth=2)
             self.own_count = 0
@@ -368,20 +374,20 @@ def main():
             s = i % a.snapshots
             G = self.G
             if self.gather_steps:
-                if G.owner(i) == rank:  # this rank builds the whole step; the root gets the maps
+                if i % world == rank:  # this rank builds the whole step (with --gather on the root gets the maps)
                     k = self.own_count % self.n_handles
                     self.own_count += 1
                     self.settle(k)
                     with torch.cuda.stream(self.streams[k]):
                         self.deposit(self.handles[k], s)
                         self.handles[k].plane_finalize()
-                        if rank != 0:
+                        if self.gather and rank != 0:
                             maps = [parallel.device_tensor(torch, self.handles[k].plane_device_maps(p)[0], npix2)
                                     for p in range(len(lds))]
                             self.pending[k] = G.send(i, maps)
                             if not self.overlap:
                                 self.settle(k)
-                elif rank == 0:
+                elif self.gather and rank == 0:
                     G.expect(i)  # (waits for the ring slot's previous occupant first)
                     if not self.overlap:
                         G.complete(i)
@@ -471,7 +477,7 @@ def main():
         L = Layout(shard, a.reduce_algo)
         dt, tot_dep, tot_in = L.run()
         Lmain = L
-    reduce_steps, gather_steps, overlap = L.reduce_steps, L.gather_steps, L.overlap
+    reduce_steps, gather_steps, overlap, gathered = L.reduce_steps, L.gather_steps, L.overlap, L.gather
     algo_mask = L.algo_mask
     n_handles, handles, my_files, my_dep = L.n_handles, L.handles, L.my_files, L.my_dep
     S0 = handles[0]
@@ -573,11 +579,21 @@ def main():
                 L2.close()
             except Exception as e:  # the main number must survive a failing secondary layout
                 reduce_layout[ralgo] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if shard == "steps" and not gathered:  # the step layout WITH the maps travelling to rank 0
+            try:
+                L2 = Layout("steps", a.reduce_algo, gather=True)
+                dt2, dep2, in2 = L2.run()
+                reduce_layout["steps_gather"] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2,
+                                                 "n_in_per_s": in2 / dt2, "overlap": L2.overlap}
+                L2.close()
+            except Exception as e:
+                reduce_layout["steps_gather"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         reduce_layout["what"] = ("--shard files: every snapshot's sub-files in contiguous ranges over the ranks "
                                  "(slicer-v2.cpp:162-175) + per-plane sum to rank 0 in the accumulator type over RCCL "
                                  "(slicer-v2.cpp:214-217); rooted = one library reduce per map, p2p = direct "
                                  "reduce-scatter + gather-to-root as grouped sends / receives (slicer_amd/parallel.py); "
-                                 "same boxes, steps and timing protocol as `value`")
+                                 "steps_gather = the step layout of `value` with every finished map also sent to rank 0 "
+                                 "point to point (parallel.StepGather); same boxes, steps and timing protocol as `value`")
 
     if rank == 0:
         out = {
@@ -605,7 +621,10 @@ def main():
                 "collective": (("per-plane sum to rank 0 in the accumulator type over RCCL, " if reduce_steps else
                                 "finished plane maps sent to rank 0 point to point over RCCL, ")
                                + ("overlapped with the following steps" if overlap else "not overlapped"))
-                if (reduce_steps or gather_steps) else None,
+                if (reduce_steps or gathered) else None,
+                "maps": ("finalized on the device of the rank that built the step (snapshots and lens planes are "
+                         "independent: no data-path collective; each rank would write its own planes)")
+                if (gather_steps and not gathered) else None,
                 "particles_in_per_step": per_file * (files if shard in ("files", "steps") else len(my_files)),
                 "particles_deposited_per_step": tot_dep / max(a.steps, 1) / (1 if shard in ("files", "steps") else world),
             },

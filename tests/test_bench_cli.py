@@ -43,9 +43,11 @@ def test_one_run_times_the_step_layout_and_the_per_plane_reduce_layout():
                                                                              "MASTER_PORT": "29533"})
     assert d["config"]["shard"] == "steps" and d["value"] > 0
     rl = d["config"]["reduce_layout"]
-    for algo in ("rooted", "p2p"):
+    assert d["config"]["collective"] is None and "no data-path collective" in d["config"]["maps"]
+    for algo in ("rooted", "p2p", "steps_gather"):
         assert "error" not in rl[algo], rl[algo]
         assert rl[algo]["value"] > 0 and rl[algo]["ms_per_step"] > 0
         # one rank: both layouts deposit the same particles, so the rates must be of the same order (the reduce of a
         # one-rank group moves nothing); a sum that stalled the pipeline would show here
-        assert rl[algo]["value"] > 0.4 * d["value"], (rl[algo], d["value"])
+        # (this tiny job is 0.2 ms per step: the fixed costs of a collective round show; the headline job: 1.9 vs 2.0 ms)
+        assert rl[algo]["value"] > 0.2 * d["value"], (rl[algo], d["value"])

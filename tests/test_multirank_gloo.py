@@ -140,7 +140,7 @@ def test_two_rank_accumulator_typed_reduce_with_a_species_missing_on_one_rank(wo
 
 
 def _worker_steps(rank, world, port, q):
-    """StepGather (bench.py's default N > 1 layout) on CPU tensors: owners build whole steps, the root collects."""
+    """StepGather (bench.py --gather on, timed in every --gpus N run as reduce_layout.steps_gather) on CPU tensors: owners build whole steps, the root collects."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
