@@ -290,14 +290,17 @@ __device__ __forceinline__ void stage_flush(const K1Args &A, unsigned *smem, uns
 // of the generic form): the common pass (TSC, constant mass, units = whole planes, one-level sort) has them compiled out.
 enum { kEmitGeneric = 0,  // NGP drop rule / band units / per-particle masses / staging, decided at run time
        kEmitLean = 1,     // TSC, constant mass, units = whole planes, one-level sort
-       kEmitSort2 = 2 };  // two-level sort (staging), the rest at run time
+       kEmitSort2 = 2,    // two-level sort (staging), the rest at run time
+       kEmitLeanNgp = 3,  // as kEmitLean with NGP's drop rule (utilities.cpp:74)
+       kEmitLeanMass = 4 };  // as kEmitLean (TSC) with per-particle masses (densitymaps.cpp:358-372)
 
 template <int MODE, bool POW2>
 __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, unsigned *s_out, unsigned *s_cnt, bool valid,
                                             int plane, float xs, float ys, int gx, int gy, unsigned idx_in_batch,
                                             uint64_t b0, float2 *out_wg, unsigned unit_stride)
 {
-    const bool ngp = MODE != kEmitLean && A.ngp != 0;
+    constexpr bool LEAN = MODE == kEmitLean || MODE == kEmitLeanNgp || MODE == kEmitLeanMass;
+    const bool ngp = MODE == kEmitLeanNgp || (!LEAN && A.ngp != 0);
     const int nn = A.nn;
     bool emit = valid;
     if (ngp) {
@@ -333,14 +336,14 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
     if (emit) {
         const unsigned ty = (unsigned)(gy >> A.th_log2), tx = (unsigned)(gx >> A.tw_log2);
         unsigned band = 0, trow = ty;
-        if (MODE != kEmitLean && A.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
+        if (!LEAN && A.units_per_plane > 1) {  // large maps: a unit is a band of tile rows
             band = ty / (unsigned)A.rows_per_unit;
             trow = ty - band * (unsigned)A.rows_per_unit;
         }
-        const unsigned unit = MODE == kEmitLean ? (unsigned)plane : (unsigned)plane * (unsigned)A.units_per_plane + band;
+        const unsigned unit = LEAN ? (unsigned)plane : (unsigned)plane * (unsigned)A.units_per_plane + band;
         // (lean emission on a power-of-two map: tile counts are powers of two, the launcher checks it -- shifts
         // instead of two quarter-rate integer multiplies)
-        const bool shifts = MODE == kEmitLean && POW2;
+        const bool shifts = LEAN && POW2;
         const unsigned tile_in_unit = shifts ? (trow << A.ntx_log2) | tx : trow * (unsigned)A.ntx + tx;
         const unsigned bin = shifts ? (unit << A.tpu_log2) | tile_in_unit : unit * (unsigned)A.tiles_per_unit + tile_in_unit;
         // one returning LDS add per lane reserves the output slot in (unit, workgroup)'s region
@@ -348,7 +351,7 @@ __device__ __forceinline__ void emit_record(const K1Args &A, unsigned *s_hist, u
         const unsigned idx = unit * unit_stride + o;
         out_wg[idx] = make_float2(xs, ys);
         A.cbin[(size_t)blockIdx.x * (size_t)A.batch + idx] = (unsigned short)tile_in_unit;
-        if (MODE != kEmitLean && A.mass != nullptr)
+        if (MODE == kEmitLeanMass || (!LEAN && A.mass != nullptr))
             A.cm[(size_t)blockIdx.x * (size_t)A.batch + idx] = A.mass[b0 + idx_in_batch];
         atomicAdd(&s_hist[bin >> 1], 1u << ((bin & 1u) * 16u));
     }
@@ -964,18 +967,26 @@ static hipError_t launch_k1_fast(bool s9, int nb, size_t lds, const PassParams &
             K1F_(S_, ST_, false, S2_);                                                \
     } while (0)
     // the lean emission where no run-time variant of it is needed (emit_record)
-    const bool lean = !A.sort2 && !A.ngp && A.units_per_plane == 1 && A.mass == nullptr &&
+    const bool lean = !A.sort2 && A.units_per_plane == 1 && !(A.mass != nullptr && A.ngp) &&
                       (!A.pow2 || (A.ntx_log2 >= 0 && A.tpu_log2 >= 0));
     if (A.sort2) {  // (never with the wave stacks: the host clears `stack` when it picks the two-level sort)
         if (s9) K1F(9, false, kEmitSort2); else K1F(15, false, kEmitSort2);
     } else if (A.stack) {
-        if (lean) {
+        if (lean && A.ngp) {
+            if (s9) K1F(9, true, kEmitLeanNgp); else K1F(15, true, kEmitLeanNgp);
+        } else if (lean && A.mass != nullptr) {
+            if (s9) K1F(9, true, kEmitLeanMass); else K1F(15, true, kEmitLeanMass);
+        } else if (lean) {
             if (s9) K1F(9, true, kEmitLean); else K1F(15, true, kEmitLean);
         } else {
             if (s9) K1F(9, true, kEmitGeneric); else K1F(15, true, kEmitGeneric);
         }
     } else {
-        if (lean) {
+        if (lean && A.ngp) {
+            if (s9) K1F(9, false, kEmitLeanNgp); else K1F(15, false, kEmitLeanNgp);
+        } else if (lean && A.mass != nullptr) {
+            if (s9) K1F(9, false, kEmitLeanMass); else K1F(15, false, kEmitLeanMass);
+        } else if (lean) {
             if (s9) K1F(9, false, kEmitLean); else K1F(15, false, kEmitLean);
         } else {
             if (s9) K1F(9, false, kEmitGeneric); else K1F(15, false, kEmitGeneric);
