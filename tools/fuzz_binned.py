@@ -10,11 +10,15 @@ S = slicer_amd.Slicer(0, max_chunk=1 << 20)
 bad = 0
 lo_seed, hi_seed = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 260)
 for seed in range(lo_seed, hi_seed):
-    try:
-        T.test_random_configurations_binned_path(S, seed)
-    except AssertionError as e:
-        bad += 1
-        print("FAIL seed", seed, str(e)[:200], flush=True)
+    for levels in (0, 1):  # one-level sort, and the two-level sort where a pass qualifies (option sort2)
+        S.set_option("sort2", levels)
+        try:
+            T.test_random_configurations_binned_path(S, levels, seed)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL seed", seed, "sort levels", levels + 1, str(e)[:200], flush=True)
+        S.plane_begin(16, 0.25, [3.0], [4.0])
+        S.set_option("sort2", 0)
     if seed % 200 == 0:
         print("seed", seed, "ok so far, failures:", bad, flush=True)
 print("done, failures:", bad)
