@@ -710,9 +710,12 @@ __device__ __forceinline__ void tile_accumulate_chunks(const PendingList &L, con
     const int tid = threadIdx.x;
     const int nn = P.nn;
 #ifndef SLICER_K4_U
-#define SLICER_K4_U 4
+#define SLICER_K4_U 2
 #endif
-    constexpr int U = SLICER_K4_U;  // records in flight per lane and round
+    // records in flight per lane and round.  A chunk brings a tile of the headline case ~1600 records: with 2 x 1024
+    // slots per round one round per chunk, no slot group that only loads clamped duplicates (A/B in one call, round 3:
+    // 450-454 us with 2 against 467-472 with 4; clustered and 2048^2 (6400 records per chunk and tile): equal)
+    constexpr int U = SLICER_K4_U;
     // (dealing the waves to the pending chunks, so that all runs stream in at once, measured 699 us against 665 us for
     // this chunk-by-chunk walk: the kernel is bound by the LDS atomic pipe, not by the loads)
     // This part's share of each chunk's run, [len*part/nparts, len*(part+1)/nparts): lane c of every wave fetches
