@@ -1001,6 +1001,25 @@ def test_explicit_binned_request_fails_loudly_when_unsupported(S):
     assert np.array_equal(cnt, nsel) and np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
 
 
+def test_replica_windows_with_per_particle_masses(S):
+    """Lateral replication beyond three per side together with per-particle masses (hydro, densitymaps.cpp:358-372): the
+    record's mass is fetched by the particle's index in its batch, which every replica window of the same chunk shares."""
+    rng = np.random.default_rng(5)
+    n0, n1 = 30000, 40000
+    pos = synth.positions(0, n0 + n1, BOX)
+    m0 = rng.uniform(0.001, 0.05, n0).astype(np.float32)
+    f = dict(npart=[n0, n1, 0, 0, 0, 0], massarr=[0.0, 0.0123, 0, 0, 0, 0], boxsize=BOX, pos=pos, mass={0: m0})
+    nrep, npix = 4, 64
+    fov = 1.96 * float(np.arctan((nrep + 0.5) / 4.0))
+    ref_tot, ref_toti, nsel = run_oracle([f], npix, fov, 3.0, 4.0, ngp=False, nrep=nrep, hydro=True)
+    (tot, toti, cnt), = run_gpu(S, [f], npix, fov, [3.0], [4.0], ngp=False, nrep=nrep, hydro=True, algo=slicer_amd.ALGO_BINNED,
+                                accum=slicer_amd.ACC_F64)
+    assert np.array_equal(cnt, nsel) and nsel[0] > 9 * n0 // 2
+    for got, ref in ((tot, ref_tot), (toti[0], ref_toti[0]), (toti[1], ref_toti[1])):
+        nz = ref > 0
+        assert float((np.abs(got[nz].astype(np.float64) - ref[nz]) / ref[nz]).max()) < tsc_gate(1.5 * 9 * nsel.sum() / npix ** 2)
+
+
 @pytest.mark.parametrize("ngp", [True, False])
 def test_up_to_32_chunks_wait_for_one_tile_launch(S, ngp):
     """The pending list holds up to 32 binned chunks (8 where a chunk brings a tile ~2048 records, more where it brings
