@@ -1348,9 +1348,18 @@ __device__ __forceinline__ void for_each_tile_cell(int W, int H, Fn &&fn)
 
 // RUNS: the pending chunks come from the two-level sort (a table of runs per tile, walked wave by wave); otherwise one
 // run per chunk (L.base), walked by the whole workgroup.
+// Registers: the TSC variants need ~54 and run two workgroups per CU.  The NGP count kernel keeps 16 pixel values per
+// lane in registers for its in-tile fold; without the species' own map (HAS_MASS slot = false) it is held to 64 registers
+// (28 bytes of scratch, touched at the file boundaries only) for the second workgroup per CU: tile kernel 615 -> 490 us,
+// --mas ngp 2.05 -> 1.92 ms per snapshot (A/B in one call, profiles/r03_k4_stage_costs.log).  With the second map (16
+// more values) the same limit spills 120 bytes and doubles the kernel's time (755 -> 1470 us): that variant stays at
+// one workgroup per CU.
+#ifndef SLICER_K4_NGP_WAVES
+#define SLICER_K4_NGP_WAVES 8
+#endif
 template <int MAS, int ACC, bool POW2, bool HAS_MASS, bool RUNS>
-__global__ __launch_bounds__(kTileBlock) void k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T,
-                                                             TileItems I, NgpFold F)
+__global__ __launch_bounds__(kTileBlock, (MAS == kNGP && ACC == kCountU32 && !HAS_MASS) ? SLICER_K4_NGP_WAVES : 4) void
+k_tile_deposit(PendingList L, PassParams P, BinGeom G, Targets T, TileItems I, NgpFold F)
 {
     using acc_t = typename AccT<ACC>::type;
     using lds_t = typename AccT<ACC>::lds;
