@@ -153,7 +153,9 @@ int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
  * slicer_plane_flush / finalize / read returns (several planes: the chunks are replayed plane by plane), so the caller's
  * later rand() calls see exactly the stream position the reference would leave.  This needs glibc's default TYPE_3
  * generator (no initstate() with another size by the process) and passes a layout self-check on a private state
- * array: 1 if so, 0 if thinning falls back to rand() calls on the host (same deviates, ~100x slower).  No GPU needed. */
+ * array: 1 if so, 0 if thinning falls back to rand() calls on the host (same deviates, ~25x slower).  No GPU needed.
+ * Reading and installing the state switches libc to a scratch state array for a few instructions (initstate / setstate):
+ * like rand() itself next to srand(), not to be raced by rand() calls of other threads of the process. */
 int slicer_libc_rand_supported(void);
 /* The process-global generator state as 31 words, oldest first (x[n-31] ... x[n-1] of x[n] = x[n-31] + x[n-3],
  * rand() = x[n] >> 1): read, and install.  Test hooks of the above; SLICER_ERR_UNSUPPORTED if not supported. */
