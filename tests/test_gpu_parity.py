@@ -808,6 +808,37 @@ def test_shot_noise_stream_on_the_device_over_many_waves(S, nrep):
     assert np.array_equal(maps[0], maps[1])
 
 
+def test_shot_noise_falls_back_to_host_rand_under_another_libc_generator(S):
+    """A process on another libc generator (initstate with 256 bytes: TYPE_4) cannot have its stream continued on the
+    device; thinning then draws with rand() on the host -- same maps as the oracle, which calls the same rand()."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    libc.initstate.restype = C.c_void_p
+    libc.initstate.argtypes = [C.c_uint, C.c_void_p, C.c_size_t]
+    libc.setstate.restype = C.c_void_p
+    libc.setstate.argtypes = [C.c_void_p]
+    big = C.create_string_buffer(256)
+    old = libc.initstate(99, big, 256)
+    try:
+        f = one_type_file(60000)
+        libc.srand(5)
+        rc, ref_tot, _, nsel = oracle.create_density_maps([f], 0, 1, 64, False, True, 3.0, 4.0, 0, 0.25, RND["sgn"],
+                                                          RND["face"], RND["center"], RND["rcase"], snopt=2)
+        after = libc.rand()
+        libc.srand(5)
+        S.plane_begin(64, 0.25, [3.0], [4.0], mas=slicer_amd.MAS_NGP, snopt=2)
+        S.file_begin(f["npart"], f["massarr"], BOX, RND["sgn"], RND["face"], RND["center"], RND["rcase"])
+        S.deposit_host(1, f["pos"])
+        S.file_end()
+        tot, _, cnt = S.plane_read(0)
+        assert libc.rand() == after
+        assert (S.algo_mask() >> 3 & 1) == 1 and (S.algo_mask() >> 8 & 1) == 0
+        assert rc == 0 and np.array_equal(cnt, nsel)
+        assert np.array_equal(tot.view(np.uint32), ref_tot.view(np.uint32))
+    finally:
+        libc.setstate(old)
+
+
 @pytest.mark.parametrize("host", [0, 1], ids=["device_stream", "host_model"])
 def test_shot_noise_with_a_stream_per_handle_equals_a_run_on_as_many_ranks(S0, host):
     """The reference's MPI ranks each own an identically seeded copy of libc's rand() stream and consume it independently,

@@ -105,3 +105,26 @@ def test_jump_matrices_agree_with_stepping():
             jumped = (jumped + ((P[:, j] * v[j]) & M)) & M
         assert [int(x) for x in jumped] == stepped
         P = mul(P, P)
+
+
+def test_another_generator_type_is_reported_and_left_alone():
+    """A process that switched libc to another generator (initstate with a 256-byte array: TYPE_4, degree 63) cannot have
+    its stream continued by the 31-word model: the library says so (thinning then draws with rand() on the host) and does
+    not disturb that generator."""
+    libc.initstate.restype = C.c_void_p
+    libc.initstate.argtypes = [C.c_uint, C.c_void_p, C.c_size_t]
+    libc.setstate.restype = C.c_void_p
+    libc.setstate.argtypes = [C.c_void_p]
+    big = C.create_string_buffer(256)
+    old = libc.initstate(4242, big, 256)
+    try:
+        a = [libc.rand() for _ in range(5)]
+        assert L.slicer_libc_rand_supported() == 0
+        v = (C.c_uint32 * 31)()
+        assert L.slicer_libc_rand_state_get(v) != 0
+        b = [libc.rand() for _ in range(5)]
+        libc.initstate(4242, big, 256)
+        assert [libc.rand() for _ in range(10)] == a + b
+    finally:
+        libc.setstate(old)
+    assert L.slicer_libc_rand_supported() == 1
