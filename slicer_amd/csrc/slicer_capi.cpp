@@ -81,6 +81,8 @@ const OptionName kOptionNames[] = {
     {"pending", "SLICER_PENDING", &Options::pending},
 };
 
+constexpr size_t kPassScalarsBytes = sizeof(unsigned long long) * SLICER_MAX_PLANES * 6 + sizeof(int) + 7 * sizeof(unsigned);
+
 struct slicer_handle_s {
     int device = 0;
     Options opt;
@@ -1394,14 +1396,15 @@ int slicer_create(int device, uint64_t max_chunk, slicer_handle *out)
     // record cursors are 32-bit: one kernel pass carries at most 2^30 particles
     h->max_chunk = max_chunk ? std::min<uint64_t>(max_chunk, 1ull << 30) : (1ull << 24);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->own) != hipSuccess ||
-        hipMalloc((void **)&h->d_counts, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6) != hipSuccess ||
-        hipMalloc((void **)&h->d_neg, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->d_maxmass, 7 * sizeof(unsigned)) != hipSuccess) {
+        // one block: the selected-entry counters, the guard flag, the mass maxima (one memset per pass clears them)
+        hipMalloc((void **)&h->d_counts, kPassScalarsBytes) != hipSuccess) {
         int rc = fail(nullptr, SLICER_ERR_HIP, "device %d initialisation failed: %s", device,
                       hipGetErrorString(hipGetLastError()));
         delete h;
         return rc;
     }
+    h->d_neg = reinterpret_cast<int *>(h->d_counts + SLICER_MAX_PLANES * 6);
+    h->d_maxmass = reinterpret_cast<unsigned *>(h->d_neg + 1);
     h->stream = h->own;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
@@ -1448,9 +1451,7 @@ int slicer_destroy(slicer_handle h)
         if (h->d_mstage[i]) (void)hipFree(h->d_mstage[i]);
         if (h->stage_free[i]) (void)hipEventDestroy(h->stage_free[i]);
     }
-    if (h->d_counts) (void)hipFree(h->d_counts);
-    if (h->d_neg) (void)hipFree(h->d_neg);
-    if (h->d_maxmass) (void)hipFree(h->d_maxmass);
+    if (h->d_counts) (void)hipFree(h->d_counts);  // (d_neg and d_maxmass live in the same block)
     if (h->own) (void)hipStreamDestroy(h->own);
     delete h;
     return SLICER_OK;
@@ -1595,9 +1596,7 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
                 return rc;
         }
     }
-    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, sizeof(unsigned long long) * SLICER_MAX_PLANES * 6, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_neg, 0, sizeof(int), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_maxmass, 0, 7 * sizeof(unsigned), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_counts, 0, kPassScalarsBytes, h->stream));  // counters, guard flag, mass maxima
     return SLICER_OK;
 }
 
