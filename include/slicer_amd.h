@@ -141,6 +141,7 @@ const char *slicer_last_error(slicer_handle h); /* valid until the next call on 
  *   ngp_general  1: no in-tile NGP fold                      dl_quot      0: no reciprocal-product grid quotient
  *   sort2        1: the two-level sort wherever a pass qualifies (default 0: the one-level sort)
  *   pending      chunks binned before one tile-kernel launch deposits them (0 = automatic: 8 ... 32)
+ *   zero_batch   1 (default): the maps of a pass are cleared by one launch; 0: one hipMemsetAsync per map
  *   thin_host    1: shot-noise deviates (snopt > 0) drawn by libc rand() on the host, one call per selected entry;
  *                default 0: the process-global rand() stream continues on the device (slicer_libc_rand_supported)
  * Unknown keys return SLICER_ERR_ARG. */

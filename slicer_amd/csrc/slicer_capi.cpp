@@ -56,6 +56,7 @@ struct Options {
     int k1_stack = -1;    // fast project+bin kernel: compact survivors through the wave stack (0 / 1; -1 = by slab depth)
     int ngp_general = 0;  // 1: no in-tile NGP fold (count map + k_fold_ngp)
     int dl_quot = 1;      // maps that are not a power of two wide: allow the swept reciprocal-product quotient
+    int zero_batch = 1;   // 1: the maps of a pass are cleared by one launch (0: one hipMemsetAsync each)
     int pending = 0;      // chunks per tile launch (0 = automatic: 8 ... 32 by the records a chunk brings per tile)
     int thin_host = 0;    // 1: shot-noise deviates drawn by libc rand() on the host (0: the stream continues on the device)
     int sort2 = 0;        // 1: two-level sort (project+bin sorts by coarse bin in LDS, k_sort2 by tile) where a pass
@@ -79,6 +80,7 @@ const OptionName kOptionNames[] = {
     {"sort2", "SLICER_SORT2", &Options::sort2},
     {"thin_host", "SLICER_THIN_HOST", &Options::thin_host},
     {"pending", "SLICER_PENDING", &Options::pending},
+    {"zero_batch", "SLICER_ZERO_BATCH", &Options::zero_batch},
 };
 
 constexpr size_t kPassScalarsBytes = sizeof(unsigned long long) * SLICER_MAX_PLANES * 6 + sizeof(int) + 7 * sizeof(unsigned);
@@ -142,6 +144,8 @@ struct slicer_handle_s {
     bool rand_on_device = false;  // between thin_rng_begin and thin_rng_end the device holds the stream
     // a stream of this handle's own instead of the process-global one (slicer_rand_stream_set): the reference's MPI
     // ranks each own an identically seeded copy of libc's stream; rank threads of one process get theirs this way
+    ZeroList zero_list{};      // zero-fills collected between zero_begin / zero_end
+    bool zero_collect = false;
     bool rand_private = false;
     uint32_t rand_state[31] = {};
     // snopt > 0 with several planes in one pass: the reference draws its deviates plane by plane (outer loop of
@@ -415,14 +419,55 @@ int pick_fixed_exp(const slicer_plane_desc &d, double m, bool has_mass)
     return frac - le;
 }
 
-int zero_async(slicer_handle h, void *p, size_t bytes)
+// Zero-fills on the handle's stream.  Between zero_begin and zero_end they are collected and go out as ONE launch
+// (launch_zero_many): a pass clears four to fourteen maps, and every dispatch costs a few microseconds of idle GPU.
+int zero_flush(slicer_handle h)
 {
-    HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
+    ZeroList &Z = h->zero_list;
+    if (Z.n == 1) {
+        HIPCHK(h, hipMemsetAsync(Z.p[0], 0, Z.words[0] * 4, h->stream));
+    } else if (Z.n > 1) {
+        HIPCHK(h, launch_zero_many(Z, h->stream));
+    }
+    Z.n = 0;
+    Z.quad0[0] = 0;
     return SLICER_OK;
 }
 
+int zero_async(slicer_handle h, void *p, size_t bytes)
+{
+    if (!h->zero_collect || (bytes & 3) || bytes == 0) {
+        HIPCHK(h, hipMemsetAsync(p, 0, bytes, h->stream));
+        return SLICER_OK;
+    }
+    ZeroList &Z = h->zero_list;
+    if (Z.n == kZeroMax) {
+        int rc = zero_flush(h);
+        if (rc)
+            return rc;
+    }
+    Z.p[Z.n] = p;
+    Z.words[Z.n] = bytes / 4;
+    Z.quad0[Z.n + 1] = Z.quad0[Z.n] + (bytes / 4 + 3) / 4;
+    Z.n++;
+    return SLICER_OK;
+}
+
+void zero_begin(slicer_handle h)
+{
+    h->zero_collect = h->opt.zero_batch != 0;
+    h->zero_list.n = 0;
+    h->zero_list.quad0[0] = 0;
+}
+
+int zero_end(slicer_handle h)
+{
+    h->zero_collect = false;
+    return zero_flush(h);
+}
+
 // Make sure the destination buffers of `type` exist and are zeroed for this plane pass.
-int prepare_type(slicer_handle h, int type, bool has_mass)
+static int prepare_type_maps(slicer_handle h, int type, bool has_mass)
 {
     const slicer_plane_desc &d = h->desc;
     const size_t n4 = h->npix2 * 4;
@@ -481,6 +526,14 @@ int prepare_type(slicer_handle h, int type, bool has_mass)
         h->type_seen[type] = true;
     }
     return SLICER_OK;
+}
+
+int prepare_type(slicer_handle h, int type, bool has_mass)
+{
+    zero_begin(h);  // the maps of all planes are cleared by one launch
+    const int rc = prepare_type_maps(h, type, has_mass);
+    const int rcz = zero_end(h);
+    return rc ? rc : rcz;
 }
 
 void fill_targets(slicer_handle h, int type, bool has_mass, Targets &T)
@@ -1586,16 +1639,16 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
         h->fixed_exp_set[t] = false;
         h->file_mode[t] = 0;
     }
-    for (int p = 0; p < desc->n_planes; p++) {
-        int rc = ensure(h, h->planes[p].tot, h->npix2 * 4);
-        if (rc)
-            return rc;
-        if (desc->mas == SLICER_MAS_NGP) {  // the NGP fold accumulates into tot; TSC finalize overwrites it
-            rc = zero_async(h, h->planes[p].tot.p, h->npix2 * 4);
-            if (rc)
-                return rc;
-        }
+    zero_begin(h);
+    int rcp = SLICER_OK;
+    for (int p = 0; p < desc->n_planes && !rcp; p++) {
+        rcp = ensure(h, h->planes[p].tot, h->npix2 * 4);
+        if (!rcp && desc->mas == SLICER_MAS_NGP)  // the NGP fold accumulates into tot; TSC finalize overwrites it
+            rcp = zero_async(h, h->planes[p].tot.p, h->npix2 * 4);
     }
+    const int rcz = zero_end(h);
+    if (rcp || rcz)
+        return rcp ? rcp : rcz;
     HIPCHK(h, hipMemsetAsync(h->d_counts, 0, kPassScalarsBytes, h->stream));  // counters, guard flag, mass maxima
     return SLICER_OK;
 }

@@ -253,6 +253,36 @@ __global__ __launch_bounds__(256) void k_thin_deposit(const float *__restrict__ 
         atomicAdd(T.nsel[0], nsel);
 }
 
+__global__ __launch_bounds__(256) void k_zero_many(ZeroList Z)
+{
+    const unsigned long long total = Z.quad0[Z.n];
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        int b = 0;
+        while (b + 1 < Z.n && q >= Z.quad0[b + 1])
+            b++;
+        const unsigned long long w = (q - Z.quad0[b]) * 4ull;  // first word of this quad inside buffer b
+        unsigned *dst = reinterpret_cast<unsigned *>(Z.p[b]) + w;
+        if (w + 4ull <= Z.words[b]) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            for (unsigned long long k = w; k < Z.words[b]; k++)
+                dst[k - w] = 0u;
+        }
+    }
+}
+
+hipError_t launch_zero_many(const ZeroList &Z, hipStream_t s)
+{
+    if (Z.n <= 0 || Z.quad0[Z.n] == 0)
+        return hipSuccess;
+    const unsigned long long total = Z.quad0[Z.n];
+    const unsigned long long want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 256ull * 32ull ? want : 256ull * 32ull);  // grid-stride beyond 32 blocks per CU
+    k_zero_many<<<grid, 256, 0, s>>>(Z);
+    return hipGetLastError();
+}
+
 static inline int grid_for(uint64_t n, int block, int per_thread = 1)
 {
     uint64_t g = (n + (uint64_t)block * per_thread - 1) / ((uint64_t)block * per_thread);

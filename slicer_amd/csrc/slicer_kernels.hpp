@@ -51,6 +51,17 @@ size_t rand_wave_states_bytes(unsigned long long max_draws);
 hipError_t launch_rand_deviates(const unsigned long long *d_nsel, uint32_t *d_state, uint32_t *d_wave_states,
                                 const void *d_tables, float *d_urand, unsigned long long max_draws, hipStream_t s);
 
+// Zero-fill of several buffers with ONE launch (the accumulator maps of a pass: one dispatch instead of one
+// hipMemsetAsync per map).  Sizes in 4-byte words; the buffers come from hipMalloc (16-byte aligned at least).
+constexpr int kZeroMax = 16;
+struct ZeroList {
+    void *p[kZeroMax];
+    unsigned long long quad0[kZeroMax + 1];  // exclusive prefix of the buffers' sizes in 16-byte quads (rounded up)
+    unsigned long long words[kZeroMax];
+    int n;
+};
+hipError_t launch_zero_many(const ZeroList &Z, hipStream_t s);
+
 // tot = sum over types / accumulator -> f32 conversion, one plane
 struct FinalizeArgs {
     const void *acc[6];  // per-type accumulators (nullptr = type never appeared)

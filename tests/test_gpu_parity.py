@@ -30,7 +30,7 @@ U24 = 2.0 ** -24
 
 
 OPTION_KEYS = ("k4_int", "tile_log2", "tile_h_log2", "bin_batch", "unit_rows", "k3_per_cu", "k1_general", "k1_stack",
-               "ngp_general", "dl_quot", "sort2", "pending", "thin_host")
+               "ngp_general", "dl_quot", "sort2", "pending", "thin_host", "zero_batch")
 
 
 @pytest.fixture(scope="module")
