@@ -1065,6 +1065,7 @@ def test_up_to_32_chunks_wait_for_one_tile_launch(S, ngp):
     ref_tot, _, nsel = run_oracle(files, npix, 0.25, 3.0, 4.0, ngp=ngp)
     for limit in (32, 8):
         S.set_option("pending", limit)
+        S.set_option("zero_batch", 1 if limit == 32 else 0)  # (the maps cleared by one launch / one memset each)
         (tot, _, cnt), = run_gpu(S, files, npix, 0.25, [3.0], [4.0], ngp=ngp, algo=slicer_amd.ALGO_BINNED)
         assert np.array_equal(cnt, nsel)
         if ngp:
@@ -1074,6 +1075,7 @@ def test_up_to_32_chunks_wait_for_one_tile_launch(S, ngp):
             assert float((np.abs(tot[nz].astype(np.float64) - ref_tot[nz]) / ref_tot[nz]).max()) < tsc_gate(
                 1.5 * 9 * nsel.sum() / npix ** 2)
     S.set_option("pending", 0)
+    S.set_option("zero_batch", 1)
 
 
 @pytest.mark.parametrize("nrep,ngp", [(4, True), (5, False), (8, True)])
