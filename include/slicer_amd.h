@@ -156,7 +156,11 @@ int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
  * generator (no initstate() with another size by the process) and passes a layout self-check on a private state
  * array: 1 if so, 0 if thinning falls back to rand() calls on the host (same deviates, ~25x slower).  No GPU needed.
  * Reading and installing the state switches libc to a scratch state array for a few instructions (initstate / setstate):
- * like rand() itself next to srand(), not to be raced by rand() calls of other threads of the process. */
+ * like rand() itself next to srand(), not to be raced by rand() calls of other threads of the process.
+ * CAUTION: once the HIP runtime runs, its own threads call rand() now and then (a kernel's first launch loads its code
+ * object, ...), which moves the process-global stream at unpredictable points.  A host that needs the reference's exact
+ * thinning reads the stream BEFORE the first HIP call of the process (slicer_libc_rand_state_get needs no GPU) and gives
+ * the handle its own copy (slicer_rand_stream_set below) -- what the createDensityMaps adapter and SLICER_amd do. */
 int slicer_libc_rand_supported(void);
 /* The process-global generator state as 31 words, oldest first (x[n-31] ... x[n-1] of x[n] = x[n-31] + x[n-3],
  * rand() = x[n] >> 1): read, and install.  Test hooks of the above; SLICER_ERR_UNSUPPORTED if not supported. */

@@ -59,12 +59,21 @@ bool ensure_handle(int myid)
     // particles per staged chunk: file reads of chunk k+1 overlap the H2D copy and kernels of chunk k, so a sub-file
     // should span several chunks (2^22: 10.8 ms per 2^24-particle sub-file end to end, against 12.5 ms at 2^24)
     const uint64_t chunk = (uint64_t)env_int("SLICER_AMD_CHUNK_LOG2", 22);
+    // Shot-noise thinning (snopt > 0, densitymaps.cpp:387-397) draws from libc's rand() stream as randomizeBox left it.
+    // This is the first call of the run (slicer-v2.cpp: randomizeBox, then the plane loop), and the last moment at which
+    // that stream is still what the reference would see: the HIP runtime's own threads call rand() now and then once it
+    // runs (a kernel's first launch loads its code object, ...).  So the stream is read BEFORE the runtime starts and the
+    // handle thins from its own copy (slicer_rand_stream_set); the process's stream stays where randomizeBox left it.
+    uint32_t stream[31];
+    const bool have_stream = slicer_libc_rand_state_get(stream) == SLICER_OK;
     int rc = slicer_create(dev, 1ull << chunk, &g.h);
     if (rc != SLICER_OK) {
         std::cerr << "slicer_amd: " << slicer_last_error(nullptr) << std::endl;
         g.h = nullptr;
         return false;
     }
+    if (have_stream)
+        (void)slicer_rand_stream_set(g.h, stream);
     g.device = dev;
     g.mas = env_int("SLICER_AMD_NGP", g.mas == SLICER_MAS_NGP) ? SLICER_MAS_NGP : SLICER_MAS_TSC;
     return true;

@@ -10,8 +10,8 @@
 //     over the snapshot (the reference re-reads and re-transforms it for each of them);   --single-plane disables
 //   * nparttype* keys carry the real selected counts (the reference writes 0: densitymaps.cpp:497), which also makes
 //     partinplanes runs write their per-type files;                                      --reference-counts disables
-//   * SubFind / halo-catalogue mode (npix == 0) is not supported; snopt > 0 forces one plane per pass; with several
-//     devices every rank thread then draws from its own copy of the libc stream, like the reference's MPI ranks
+//   * SubFind / halo-catalogue mode (npix == 0) is not supported; with snopt > 0 and several devices every rank thread
+//     draws from its own copy of the libc stream, like the reference's MPI ranks
 //     (the thinning deviates come from the process-global libc rand() stream, densitymaps.cpp:387-397: the reference's
 //     MPI ranks each own an identically seeded copy of it, host threads of one process would interleave their draws).
 #include <dlfcn.h>
@@ -68,8 +68,19 @@ void dump_plan(const string &path, const InputParams &p, const Lens &lens, const
     FILE *f = fopen(path.c_str(), "w");
     if (!f)
         return;
-    fprintf(f, "{\n \"Ds\": %.17g, \"fovradiants\": %.17g, \"nplanes\": %d, \"hydro\": %d,\n \"planes\": [\n", p.Ds,
-            fovradiants, lens.nplanes, (int)p.hydro);
+    fprintf(f, "{\n \"Ds\": %.17g, \"fovradiants\": %.17g, \"nplanes\": %d, \"hydro\": %d,\n", p.Ds, fovradiants,
+            lens.nplanes, (int)p.hydro);
+    // the process's libc rand() stream as randomizeBox left it (31 words, oldest first): what shot-noise thinning
+    // (snopt > 0) starts to draw from -- null where the C library does not expose it
+    uint32_t v[31];
+    if (slicer_libc_rand_state_get(v) == SLICER_OK) {
+        fprintf(f, " \"libc_rand_state\": [");
+        for (int i = 0; i < 31; i++)
+            fprintf(f, "%u%s", v[i], i < 30 ? ", " : "],\n");
+    } else {
+        fprintf(f, " \"libc_rand_state\": null,\n");
+    }
+    fprintf(f, " \"planes\": [\n");
     for (int i = 0; i < lens.nplanes; i++) {
         fprintf(f,
                 "  {\"ld\": %.17g, \"ld2\": %.17g, \"zsimlens\": %.17g, \"fromsnap\": \"%s\", \"fromsnapi\": %d, "
@@ -353,8 +364,9 @@ int main(int argc, char **argv)
         dump_plan(plan_path, p, lens, random, snapbox, fovradiants);
     if (plan_only)
         return 0;
-    if (p.snopt != 0)
-        single_plane = true;  // thinning consumes libc rand() plane by plane (densitymaps.cpp:387-397)
+    // (snopt > 0: thinning consumes libc rand() plane by plane, densitymaps.cpp:387-397.  A pass over several planes
+    // keeps that order -- the library replays its chunks plane-major when the pass ends -- so the planes of a box
+    // replication still share one read of the snapshot.)
 
     vector<int> devs = devices_spec.empty() ? vector<int>{device} : parse_devices(devices_spec);
     if (devs.empty() || (reduce_mode != "rccl" && reduce_mode != "host") ||
@@ -368,12 +380,19 @@ int main(int argc, char **argv)
     // handle gets a stream of its own, started from the process state as randomizeBox left it -- the run then equals a
     // reference run on as many MPI ranks.  Where that state cannot be read (no glibc TYPE_3 generator) the combination
     // stays refused.
+    // The same with ONE device: the stream is taken here, before the HIP runtime starts, and the handle thins from its
+    // copy -- the runtime's own threads call rand() now and then (code-object loading at a kernel's first launch, ...),
+    // which moves the process-global stream at unpredictable points of a run (round 3: planes of a cone differed from
+    // run to run until the driver stopped drawing from the shared stream).
     uint32_t rank_stream[31];
-    const bool private_streams = p.snopt != 0 && devs.size() > 1;
+    bool private_streams = p.snopt != 0;
     if (private_streams && slicer_libc_rand_state_get(rank_stream) != SLICER_OK) {
-        cerr << "snopt > 0 on several devices needs per-rank copies of the libc rand() stream, which this C library does "
-                "not expose (slicer_libc_rand_supported() == 0): use a single device" << endl;
-        return 2;
+        if (devs.size() > 1) {
+            cerr << "snopt > 0 on several devices needs per-rank copies of the libc rand() stream, which this C library "
+                    "does not expose (slicer_libc_rand_supported() == 0): use a single device" << endl;
+            return 2;
+        }
+        private_streams = false;  // one device: the process-global stream, drawn with rand() on the host
     }
     const int rccl_algo = reduce_algo == "direct" ? SLICER_RCCL_REDUCE_DIRECT : SLICER_RCCL_REDUCE_ROOTED;
     vector<Rank> ranks(devs.size());

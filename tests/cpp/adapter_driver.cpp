@@ -24,7 +24,14 @@ int main(int argc, char **argv)
     p.npix = atoi(argv[4]);
     p.hydro = atoi(argv[10]) != 0;
     p.simType = "Gadget";
-    p.snopt = 0;
+    // ADAPTER_SNOPT=k: shot-noise thinning; ADAPTER_SRAND=seed: the libc stream as randomizeBox would leave it (srand +
+    // five draws), set before the first createDensityMaps call -- i.e. before the HIP runtime starts
+    p.snopt = getenv("ADAPTER_SNOPT") ? atoi(getenv("ADAPTER_SNOPT")) : 0;
+    if (getenv("ADAPTER_SRAND")) {
+        srand((unsigned)atoi(getenv("ADAPTER_SRAND")));
+        for (int i = 0; i < 5; i++)
+            (void)rand();
+    }
     p.partinplanes = getenv("ADAPTER_PARTINPLANES") ? atoi(getenv("ADAPTER_PARTINPLANES")) != 0 : true;
     auto split = [](const char *a) {
         std::vector<double> v;

@@ -129,3 +129,33 @@ def test_adapter_can_skip_the_per_type_maps_the_caller_discards(tmp_path):
                     assert np.array_equal(raw[1:].view(np.uint32), toti.view(np.uint32))
             else:
                 assert not raw[1:].any()
+
+
+@pytest.mark.gpu
+def test_adapter_shot_noise_follows_the_stream_randomizebox_left(tmp_path):
+    """snopt > 0 through the C++ adapter in a fresh process: the adapter reads libc's rand() stream at its first call --
+    before the HIP runtime starts, whose threads draw from that stream now and then -- and thins from its own copy, plane
+    after plane.  NGP maps bit for bit like the oracle started from the same srand + five draws."""
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    npix, fov, rcase = 64, 0.25, 3.0
+    base, files = make_files(tmp_path, False)
+    lds, ld2s = [3.0, 3.3, 3.6], [3.3, 3.6, 4.0]
+    out = str(tmp_path / "maps.bin")
+    env = dict(os.environ, ADAPTER_SNOPT="2", ADAPTER_SRAND="777")
+    r = subprocess.run([DRIVER, base, "0", "2", str(npix), repr(fov), ",".join(map(repr, lds)), ",".join(map(repr, ld2s)),
+                        repr(rcase), "1", "0", out], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    per_plane = 7 * npix * npix * 4 + 6 * 4
+    blob = open(out, "rb").read()
+    assert len(blob) == 3 * per_plane
+    libc.srand(777)
+    for _ in range(5):
+        libc.rand()
+    for p in range(3):
+        rc, ref_tot, ref_toti, nsel = oracle.create_density_maps(files, 0, 2, npix, False, True, lds[p], ld2s[p], 0, fov,
+                                                                 (-1, 1, -1), 3, (0.3, 0.6, 0.1), rcase, snopt=2)
+        assert rc == 0 and nsel.sum() > 0
+        raw = np.frombuffer(blob, np.float32, 7 * npix * npix, offset=p * per_plane).reshape(7, npix, npix)
+        assert np.array_equal(raw[0].view(np.uint32), ref_tot.view(np.uint32)), p
+        assert np.array_equal(raw[1:].view(np.uint32), ref_toti.view(np.uint32)), p

@@ -210,6 +210,38 @@ def test_a_rank_that_fails_locally_stops_every_rank_before_the_collective(tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("single_plane", [False, True])
+def test_shot_noise_thinning_through_the_driver_matches_the_oracle(tmp_path, single_plane):
+    """snopt > 0 end to end: the plan carries libc's rand() state as randomizeBox left it; the oracle, started from that
+    state and run plane after plane, must give every FITS plane bit for bit (NGP) -- with the planes of a box replication
+    in ONE pass (the library replays the pass plane-major) and with one pass per plane."""
+    libc = C.CDLL("libc.so.6")
+    from slicer_amd import _lib
+    L = _lib.load()
+    ini, files, out = make_cone(tmp_path, snopt=2)
+    plan_path = str(tmp_path / "plan.json")
+    r = run([ini, "--ngp", "--dump-plan", plan_path] + (["--single-plane"] if single_plane else []))
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.load(open(plan_path))
+    assert plan["libc_rand_state"] is not None and len(plan["libc_rand_state"]) == 31
+    assert L.slicer_libc_rand_state_set((C.c_uint32 * 31)(*plan["libc_rand_state"])) == 0
+    rcase, thinned = 0.0, 0
+    for i, pl in enumerate(plan["planes"]):
+        if pl["randomize"]:
+            rcase = float(np.float32(pl["ld"] / pl["snapbox"] * 1e3))
+        rc, tot, toti, nsel = oracle.create_density_maps(files[pl["fromsnap"]], 0, 2, 32, False, True, pl["ld"], pl["ld2"], 0,
+                                                         plan["fovradiants"], pl["sgn"], pl["face"],
+                                                         (pl["x0"], pl["y0"], pl["z0"]), rcase, snopt=2)
+        assert rc == 0
+        raw = open(os.path.join(out, "cone_gadget.%03d.plane_32_t0.fits" % i), "rb").read()
+        data = np.frombuffer(raw[2880:2880 + 4 * 1024], ">f4").reshape(32, 32).astype(np.float32)
+        assert np.array_equal(data.view(np.uint32), tot.view(np.uint32)), i
+        assert (b"HIERARCH NPARTTYPE1 = %8d" % nsel[1]) in raw[:2880]
+        thinned += int(nsel.sum())
+    assert thinned > 300  # (a 2-degree cone: few entries per plane, every one of them drawn for)
+
+
+@pytest.mark.gpu
 def test_shot_noise_thinning_on_several_devices_is_reproducible(tmp_path):
     """snopt > 0 draws from libc's rand() stream (densitymaps.cpp:387-397).  The reference's MPI ranks each own an
     identically seeded copy of it; the rank threads of this process each get one as well (slicer_rand_stream_set, started
