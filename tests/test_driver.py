@@ -166,6 +166,32 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("accum", ["f32", "f64", "fixed64"])
+def test_full_run_with_tsc_stays_inside_the_tolerance(tmp_path, accum):
+    """The default mass assignment (TSC, densitymaps.h:22 DO_NGP false) through the whole driver, every accumulator
+    type: each FITS plane within the T-TSC bar of the oracle's map, zero pixels where the oracle has zeros."""
+    ini, files, out = make_cone(tmp_path)
+    plan_path = str(tmp_path / "plan.json")
+    r = run([ini, "--accum", accum, "--dump-plan", plan_path])
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.load(open(plan_path))
+    rcase = 0.0
+    for i, pl in enumerate(plan["planes"]):
+        if pl["randomize"]:
+            rcase = float(np.float32(pl["ld"] / pl["snapbox"] * 1e3))
+        rc, tot, toti, nsel = oracle.create_density_maps(files[pl["fromsnap"]], 0, 2, 32, False, False, pl["ld"], pl["ld2"], 0,
+                                                         plan["fovradiants"], pl["sgn"], pl["face"],
+                                                         (pl["x0"], pl["y0"], pl["z0"]), rcase)
+        assert rc == 0
+        raw = open(os.path.join(out, "cone_gadget.%03d.plane_32_t0.fits" % i), "rb").read()
+        data = np.frombuffer(raw[2880:2880 + 4 * 1024], ">f4").reshape(32, 32).astype(np.float64)
+        assert np.array_equal(data == 0, tot == 0), i
+        # FIXED64 resolves 2^-40 of the mass scale absolutely: a pixel of 1e-9 carries that as a relative 1e-4
+        slack = 1e-11 if accum == "fixed64" else 0.0
+        assert np.all(np.abs(data - tot) <= 3e-6 * tot + slack), i
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("partinplanes", [0, 1])
 def test_two_rank_driver_equals_one_rank_bitwise_with_fixed64(tmp_path, partinplanes):
     """slicer-v2.cpp:162-175 + 214-217 in the driver: `--devices 0,0` runs two ranks (two handles, one host thread each;
