@@ -185,7 +185,9 @@ def test_full_run_with_tsc_stays_inside_the_tolerance(tmp_path, accum):
         assert rc == 0
         raw = open(os.path.join(out, "cone_gadget.%03d.plane_32_t0.fits" % i), "rb").read()
         data = np.frombuffer(raw[2880:2880 + 4 * 1024], ">f4").reshape(32, 32).astype(np.float64)
-        assert np.array_equal(data == 0, tot == 0), i
+        assert np.all(data[tot == 0] == 0), i
+        if accum != "fixed64":  # (a contribution below the fixed-point quantum rounds to zero there)
+            assert np.array_equal(data == 0, tot == 0), i
         # FIXED64 resolves 2^-40 of the mass scale absolutely: a pixel of 1e-9 carries that as a relative 1e-4
         slack = 1e-11 if accum == "fixed64" else 0.0
         assert np.all(np.abs(data - tot) <= 3e-6 * tot + slack), i
