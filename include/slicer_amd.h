@@ -149,16 +149,20 @@ int slicer_set_option(slicer_handle h, const char *key, int32_t value);
 int slicer_get_option(slicer_handle h, const char *key, int32_t *value);
 
 /* Shot-noise thinning (InputParams.snopt > 0) consumes the process-global libc rand() stream, one deviate per selected
- * entry (densitymaps.cpp:393).  The library continues that stream on the device -- it reads the generator state, jumps
- * and generates there, and installs the advanced state before the depositing call returns (single plane) or before
- * slicer_plane_flush / finalize / read returns (several planes: the chunks are replayed plane by plane), so the caller's
- * later rand() calls see exactly the stream position the reference would leave.  This needs glibc's default TYPE_3
- * generator (no initstate() with another size by the process) and passes a layout self-check on a private state
+ * entry (densitymaps.cpp:393).  The library continues that stream on the device: slicer_plane_begin of a pass with
+ * snopt > 0 reads the generator state (before it touches the HIP runtime), the pass jumps and generates from that copy on
+ * the GPU, and the advanced state is installed in libc when the pass ends -- before slicer_plane_flush / finalize / read
+ * returns (or the next slicer_plane_begin, or slicer_destroy) -- so the caller's rand() calls after the pass see exactly
+ * the stream position the reference would leave.  The host must not draw from rand() itself between plane_begin and
+ * that point.  This needs glibc's default TYPE_3 generator (no initstate() with another size by the process) and passes
+ * a layout self-check on a private state
  * array: 1 if so, 0 if thinning falls back to rand() calls on the host (same deviates, ~25x slower).  No GPU needed.
  * Reading and installing the state switches libc to a scratch state array for a few instructions (initstate / setstate):
  * like rand() itself next to srand(), not to be raced by rand() calls of other threads of the process.
  * CAUTION: once the HIP runtime runs, its own threads call rand() now and then (a kernel's first launch loads its code
- * object, ...), which moves the process-global stream at unpredictable points.  A host that needs the reference's exact
+ * object, allocations, ...), which moves the process-global stream at unpredictable points.  What they draw DURING a pass
+ * is overwritten when the pass ends; what they draw between the host's own last draw and slicer_plane_begin (any HIP
+ * work of the process in that window: creating the handle, other passes) is not.  A host that needs the reference's exact
  * thinning reads the stream BEFORE the first HIP call of the process (slicer_libc_rand_state_get needs no GPU) and gives
  * the handle its own copy (slicer_rand_stream_set below) -- what the createDensityMaps adapter and SLICER_amd do. */
 int slicer_libc_rand_supported(void);

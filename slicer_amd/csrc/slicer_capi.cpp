@@ -148,6 +148,11 @@ struct slicer_handle_s {
     bool zero_collect = false;
     bool rand_private = false;
     uint32_t rand_state[31] = {};
+    // Process-global mode (no slicer_rand_stream_set): the process's stream is read when a pass with snopt > 0 BEGINS --
+    // before that call touches the HIP runtime, whose threads draw from libc's stream themselves now and then -- the pass
+    // thins from this copy, and the advanced state goes back to libc when the pass ends (flush / finalize / read, the next
+    // plane_begin, destroy): whatever the runtime drew in between is overwritten.
+    bool rand_pass = false;
     // snopt > 0 with several planes in one pass: the reference draws its deviates plane by plane (outer loop of
     // createDensityMaps' caller), so the chunks are kept on the device and deposited plane-major when the pass ends
     struct ThinChunk {
@@ -924,6 +929,15 @@ int flush_pending(slicer_handle h)
     return SLICER_OK;
 }
 
+// End of a pass in process-global mode: libc gets its stream back, advanced by the pass's draws.
+void pass_stream_return(slicer_handle h)
+{
+    if (h->rand_pass) {
+        (void)libc_rand_put(h->rand_state);
+        h->rand_pass = false;
+    }
+}
+
 // The libc stream moves to the device for a run of thinned chunks: thin_rng_begin reads the process-global generator
 // state and uploads it, thin_rng_end brings the advanced state back and installs it (one synchronisation).  False from
 // begin: the stream stays on the host (option thin_host, a generator other than glibc's TYPE_3, or the layout check of
@@ -934,7 +948,7 @@ bool thin_rng_begin(slicer_handle h, int &rc)
     if (h->opt.thin_host)
         return false;
     uint32_t v[31];
-    if (h->rand_private)
+    if (h->rand_private || h->rand_pass)
         memcpy(v, h->rand_state, sizeof v);
     else if (!libc_rand_grab(v))
         return false;
@@ -964,7 +978,7 @@ int thin_rng_end(slicer_handle h)
     uint32_t v[31];
     HIPCHK(h, hipMemcpyAsync(v, h->w_randstate.p, sizeof v, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->rand_private)
+    if (h->rand_private || h->rand_pass)
         memcpy(h->rand_state, v, sizeof v);
     else if (!libc_rand_put(v))
         return fail(h, SLICER_ERR_STATE, "the process changed its libc generator during a thinned pass");
@@ -1013,7 +1027,7 @@ int thin_chunk(slicer_handle h, PassParams P, const Targets &T, const LaunchCfg 
     HIPCHK(h, hipMemcpyAsync(&nsel, d_nsel, sizeof nsel, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->h_urand.resize(nsel);
-    if (h->rand_private)
+    if (h->rand_private || h->rand_pass)
         libc_rand_model_fill(h->rand_state, h->h_urand.data(), nsel);
     else
         for (unsigned long long k = 0; k < nsel; k++)
@@ -1070,7 +1084,18 @@ int fold_file_plane(slicer_handle h, int p)
 
 // snopt > 0 with several planes: deposit the retained chunks plane-major, files and species in their original order
 // inside each plane -- the order in which the reference (one createDensityMaps call per plane) consumes rand().
+static int thin_replay_chunks(slicer_handle h);
+
+// Called wherever a pass ends (flush / finalize / read): deposits the retained chunks of a multi-plane thinned pass and
+// hands libc its stream back.
 int thin_replay(slicer_handle h)
+{
+    const int rc = thin_replay_chunks(h);
+    pass_stream_return(h);
+    return rc;
+}
+
+static int thin_replay_chunks(slicer_handle h)
 {
     if (!thin_deferred(h) || (h->thin_chunks.empty() && h->thin_files.empty()))
         return SLICER_OK;
@@ -1474,6 +1499,7 @@ int slicer_destroy(slicer_handle h)
     (void)hipStreamSynchronize(h->stream);
     prof_collect(h);
     thin_drop(h);
+    pass_stream_return(h);
     for (auto e : h->ev_pool)
         (void)hipEventDestroy(e);
     for (auto &pl : h->planes) {
@@ -1547,6 +1573,7 @@ int slicer_rand_stream_set(slicer_handle h, const uint32_t *v31)
         return fail(h, SLICER_ERR_ARG, "null handle");
     if (h->in_file)
         return fail(h, SLICER_ERR_STATE, "slicer_rand_stream_set inside a file");
+    pass_stream_return(h);
     h->rand_private = v31 != nullptr;
     if (v31)
         memcpy(h->rand_state, v31, sizeof h->rand_state);
@@ -1612,6 +1639,10 @@ int slicer_plane_begin(slicer_handle h, const slicer_plane_desc *desc)
     for (int p = 0; p < desc->n_planes; p++)
         if (desc->nrepperp[p] < 0 || desc->nrepperp[p] > 8)
             return fail(h, SLICER_ERR_ARG, "nrepperp[%d] = %d out of range 0..8", p, desc->nrepperp[p]);
+    // shot-noise thinning in process-global mode: libc's stream is read here, before this call touches the HIP runtime
+    pass_stream_return(h);  // (a pass that was never read or flushed)
+    if (desc->snopt > 0 && !h->rand_private && libc_rand_grab(h->rand_state))
+        h->rand_pass = true;
     HIPCHK(h, hipSetDevice(h->device));
     h->desc = *desc;
     h->dl_quot_ok = false;

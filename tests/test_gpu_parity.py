@@ -13,6 +13,7 @@ Every run that names an algorithm also asserts that THAT algorithm ran (slicer_p
 BINNED request never falls back to the fused global-atomic kernel silently.
 """
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -806,6 +807,20 @@ def test_shot_noise_stream_on_the_device_over_many_waves(S, nrep):
         maps.append(tot)
     S.set_option("thin_host", 0)
     assert np.array_equal(maps[0], maps[1])
+
+
+def test_shot_noise_in_fresh_processes_survives_the_runtimes_own_rand_calls():
+    """The HIP runtime's threads draw from libc's rand() stream themselves (allocations, code-object loading, ...): in a
+    process's FIRST thinned pass all of that happens between the host's srand() and the last deposit.  The pass reads the
+    stream at slicer_plane_begin, before it touches the runtime, and puts the advanced state back at the end -- the map,
+    the counters and the stream position afterwards must be the oracle's, process after process."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "fresh_process_thinning.py")
+    for _ in range(3):
+        r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "THINNING_OK" in r.stdout, r.stdout[-300:]
 
 
 def test_shot_noise_falls_back_to_host_rand_under_another_libc_generator(S):
