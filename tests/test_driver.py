@@ -21,21 +21,28 @@ EXE = os.path.join(ROOT, "slicer_amd", "SLICER_amd")
 BOX = 100000.0  # kpc/h
 
 
-def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0):
+def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0, hydro=False):
     snaps = [("snapdir_003/snap_003", 0.0), ("snapdir_002/snap_002", 0.1), ("snapdir_001/snap_001", 0.25)]
     files = {}
     first = 0
+    rng = np.random.default_rng(11)
     for name, z in snaps:
         os.makedirs(tmp_path / os.path.dirname(name), exist_ok=True)
         fl = []
         for ff in range(2):
-            npart = [0, 3000 + 7 * ff, 501, 0, 0, 0]
+            # hydro: gas (type 0) with massarr[0] = 0 and a MASS block -- per-particle masses, some above MAX_M
+            npart = [2000 + 3 * ff if hydro else 0, 3000 + 7 * ff, 501, 0, 0, 0]
             n = sum(npart)
             pos = synth.positions(first, n, BOX)
             first += n
+            m0 = None
+            if hydro:
+                m0 = rng.uniform(0.001, 0.05, npart[0]).astype(np.float32)
+                m0[::211] = 2000.0
             gadget.write_snapshot(str(tmp_path / f"{name}.{ff}"), pos, npart, [0, 0.0123, 0.3, 0, 0, 0], BOX, numfiles=2,
-                                  redshift=z, om0=0.3, oml=0.7, h=0.7)
-            fl.append(dict(npart=npart, massarr=[0, 0.0123, 0.3, 0, 0, 0], boxsize=BOX, pos=pos))
+                                  redshift=z, om0=0.3, oml=0.7, h=0.7, **({"mass": m0} if hydro else {}))
+            fl.append(dict(npart=npart, massarr=[0, 0.0123, 0.3, 0, 0, 0], boxsize=BOX, pos=pos,
+                           **({"mass": {0: m0}} if hydro else {})))
         files[name] = fl
     (tmp_path / "snapshot_list.txt").write_text("\n".join(n for n, _ in snaps))
     out = tmp_path / "out"
@@ -163,6 +170,40 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
         for f in os.listdir(out):
             if f.endswith(".fits"):
                 assert open(os.path.join(out, f), "rb").read() == open(os.path.join(out, f + ".multi"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_full_run_with_per_particle_masses(tmp_path):
+    """A hydro snapshot through the whole driver (testHydro: a species with npart > 0 and massarr = 0 carries a MASS
+    block; densitymaps.cpp:358-372 reads one mass per particle, MAX_M zeroes the outliers), with per-type files
+    (partinplanes): the constant-mass species bit for bit (NGP), the gas map and the total inside the f32 bar."""
+    ini, files, out = make_cone(tmp_path, partinplanes=1, hydro=True)
+    plan_path = str(tmp_path / "plan.json")
+    r = run([ini, "--ngp", "--dump-plan", plan_path])
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.load(open(plan_path))
+    assert plan["hydro"] == 1
+    rcase, gas = 0.0, 0
+    for i, pl in enumerate(plan["planes"]):
+        if pl["randomize"]:
+            rcase = float(np.float32(pl["ld"] / pl["snapbox"] * 1e3))
+        rc, tot, toti, nsel = oracle.create_density_maps(files[pl["fromsnap"]], 0, 2, 32, True, True, pl["ld"], pl["ld2"], 0,
+                                                         plan["fovradiants"], pl["sgn"], pl["face"],
+                                                         (pl["x0"], pl["y0"], pl["z0"]), rcase)
+        assert rc == 0
+        for t in (0, 1, 2):
+            path = os.path.join(out, "cone_gadget.%03d.ptype%d_plane_32_t0.fits" % (i, t))
+            if nsel[t] == 0:
+                assert not os.path.exists(path)
+                continue
+            raw = open(path, "rb").read()
+            data = np.frombuffer(raw[2880:2880 + 4 * 1024], ">f4").reshape(32, 32).astype(np.float32)
+            if t == 0:
+                gas += int(nsel[0])
+                assert np.all(np.abs(data.astype(np.float64) - toti[0]) <= 3e-6 * toti[0]), (i, t)
+            else:
+                assert np.array_equal(data.view(np.uint32), toti[t].view(np.uint32)), (i, t)
+    assert gas > 100
 
 
 @pytest.mark.gpu
