@@ -173,6 +173,33 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
 
 
 @pytest.mark.gpu
+def test_full_run_with_a_physical_pixel_size(tmp_path):
+    """npix < 0 in the parameter file asks for pixels of -npix kpc/h: every plane gets its own map size
+    (slicer-v2.cpp:142-143: int(mean distance * fov / rgrid * 1e3) + 1) and the files carry "<n>_kpc" in their names.
+    Each plane bit for bit (NGP) like the oracle at that plane's size."""
+    ini, files, out = make_cone(tmp_path, npix=-150)
+    plan_path = str(tmp_path / "plan.json")
+    r = run([ini, "--ngp", "--dump-plan", plan_path])
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.load(open(plan_path))
+    rcase, sizes = 0.0, set()
+    for i, pl in enumerate(plan["planes"]):
+        if pl["randomize"]:
+            rcase = float(np.float32(pl["ld"] / pl["snapbox"] * 1e3))
+        npix = int((pl["ld2"] + pl["ld"]) / 2 * plan["fovradiants"] / 150 * 1e3 / 1.0) + 1
+        sizes.add(npix)
+        rc, tot, toti, nsel = oracle.create_density_maps(files[pl["fromsnap"]], 0, 2, npix, False, True, pl["ld"], pl["ld2"], 0,
+                                                         plan["fovradiants"], pl["sgn"], pl["face"],
+                                                         (pl["x0"], pl["y0"], pl["z0"]), rcase)
+        assert rc == 0
+        raw = open(os.path.join(out, "cone_gadget.%03d.plane_150_kpc_t0.fits" % i), "rb").read()
+        assert (b"NAXIS1  = %20d" % npix) in raw[:2880] and (b"NAXIS2  = %20d" % npix) in raw[:2880]
+        data = np.frombuffer(raw[2880:2880 + 4 * npix * npix], ">f4").reshape(npix, npix).astype(np.float32)
+        assert np.array_equal(data.view(np.uint32), tot.view(np.uint32)), i
+    assert len(sizes) > 5 and max(sizes) > 3 * min(sizes)
+
+
+@pytest.mark.gpu
 def test_full_run_with_per_particle_masses(tmp_path):
     """A hydro snapshot through the whole driver (testHydro: a species with npart > 0 and massarr = 0 carries a MASS
     block; densitymaps.cpp:358-372 reads one mass per particle, MAX_M zeroes the outliers), with per-type files
