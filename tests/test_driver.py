@@ -21,7 +21,7 @@ EXE = os.path.join(ROOT, "slicer_amd", "SLICER_amd")
 BOX = 100000.0  # kpc/h
 
 
-def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0, hydro=False):
+def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0, hydro=False, fov=2.0):
     snaps = [("snapdir_003/snap_003", 0.0), ("snapdir_002/snap_002", 0.1), ("snapdir_001/snap_001", 0.25)]
     files = {}
     first = 0
@@ -47,7 +47,7 @@ def make_cone(tmp_path, npix=32, partinplanes=0, zs=0.2, snopt=0, hydro=False):
     (tmp_path / "snapshot_list.txt").write_text("\n".join(n for n, _ in snaps))
     out = tmp_path / "out"
     out.mkdir()
-    vals = [npix, zs, 2.0, str(tmp_path / "snapshot_list.txt"), str(tmp_path) + "/", "gadget", -229, -230, -231,
+    vals = [npix, zs, fov, str(tmp_path / "snapshot_list.txt"), str(tmp_path) + "/", "gadget", -229, -230, -231,
             partinplanes, str(out) + "/cone_", "t0", snopt, -1.0]
     ini = tmp_path / "InputParams.ini"
     ini.write_text("".join(f"##### {i + 1}. #####\n{v}\n" for i, v in enumerate(vals)))
@@ -170,6 +170,36 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
         for f in os.listdir(out):
             if f.endswith(".fits"):
                 assert open(os.path.join(out, f), "rb").read() == open(os.path.join(out, f + ".multi"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_full_run_with_lateral_replication(tmp_path):
+    """--replication (the reference's -DReplicationOnPerpendicularPlane): a 60-degree field is wider than the box from the
+    second box replication on, so the planner gives the far planes lateral copies of the box (computeReplications) and the
+    deposit emits every copy inside the field (densitymaps.cpp:377-401).  Without the flag the same field is refused."""
+    ini, files, out = make_cone(tmp_path, fov=60.0)
+    r0 = run([ini, "--plan-only"])
+    assert r0.returncode == 1 and "Field view too large" in r0.stderr
+    plan_path = str(tmp_path / "plan.json")
+    r = run([ini, "--ngp", "--replication", "--dump-plan", plan_path])
+    assert r.returncode == 0, r.stderr[-2000:]
+    plan = json.load(open(plan_path))
+    reps = [pl["nrepperp"] for pl in plan["planes"]]
+    assert reps[0] == 0 and max(reps) >= 3 and reps == sorted(reps)
+    rcase = 0.0
+    for i, pl in enumerate(plan["planes"]):
+        if pl["randomize"]:
+            rcase = float(np.float32(pl["ld"] / pl["snapbox"] * 1e3))
+        rc, tot, toti, nsel = oracle.create_density_maps(files[pl["fromsnap"]], 0, 2, 32, False, True, pl["ld"], pl["ld2"],
+                                                         pl["nrepperp"], plan["fovradiants"], pl["sgn"], pl["face"],
+                                                         (pl["x0"], pl["y0"], pl["z0"]), rcase)
+        assert rc == 0
+        raw = open(os.path.join(out, "cone_gadget.%03d.plane_32_t0.fits" % i), "rb").read()
+        data = np.frombuffer(raw[2880:2880 + 4 * 1024], ">f4").reshape(32, 32).astype(np.float32)
+        assert np.array_equal(data.view(np.uint32), tot.view(np.uint32)), (i, pl["nrepperp"])
+        assert (b"HIERARCH NPARTTYPE1 = %8d" % nsel[1]) in raw[:2880]
+        if pl["nrepperp"] >= 3:
+            assert nsel[1] > 6000   # more entries than the snapshot has particles of the species
 
 
 @pytest.mark.gpu
