@@ -132,6 +132,43 @@ def test_adapter_can_skip_the_per_type_maps_the_caller_discards(tmp_path):
 
 
 @pytest.mark.gpu
+def test_adapter_streams_black_hole_masses_from_bhma(tmp_path):
+    """densitymaps.cpp:358-372: per-particle masses stream from the MASS block in type order, except type 5, which skips its
+    entries there and streams from BHMA.  Through the C++ reader and adapter: gas and black holes with per-particle
+    masses next to two constant-mass species, every per-type map against the oracle."""
+    npix, fov, ld, ld2, rcase = 64, 0.25, 3.0, 4.0, 3.0
+    base = str(tmp_path / "snap_077")
+    rng = np.random.default_rng(21)
+    files, first = [], 0
+    for ff in range(2):
+        npart = [3001 + ff, 40003, 0, 1201, 0, 907]
+        n = sum(npart)
+        pos = synth.positions(first, n, BOX)
+        first += n
+        massarr = [0.0, 0.0123, 0, 0.3, 0, 0.0]
+        m0 = rng.uniform(0.01, 0.03, npart[0]).astype(np.float32)
+        bh = rng.uniform(0.5, 5.0, npart[5]).astype(np.float32)
+        # MASS holds an entry for every particle of a massarr == 0 species, type 5 included (its entries are skipped)
+        mass_block = np.concatenate([m0, np.full(npart[5], 123.0, np.float32)])
+        gadget.write_snapshot(f"{base}.{ff}", pos, npart, massarr, BOX, numfiles=2, mass=mass_block, bhmass=bh)
+        files.append(dict(npart=npart, massarr=massarr, boxsize=BOX, pos=pos, mass={0: m0, 5: bh}))
+    out = str(tmp_path / "maps.bin")
+    r = run_driver(base, 0, 2, npix, fov, ld, ld2, rcase, True, True, out)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(out, np.float32, 7 * npix * npix).reshape(7, npix, npix)
+    rc, tot, toti, nsel = oracle.create_density_maps(files, 0, 2, npix, True, True, ld, ld2, 0, fov, (-1, 1, -1), 3,
+                                                     (0.3, 0.6, 0.1), rcase)
+    assert rc == 0 and nsel[5] > 100 and nsel[0] > 100
+    for t in (1, 3):  # constant-mass species: bit for bit under NGP
+        assert np.array_equal(raw[1 + t].view(np.uint32), toti[t].view(np.uint32)), t
+    for t in (0, 5):
+        d = np.abs(raw[1 + t].astype(np.float64) - toti[t])
+        assert np.all(d <= 3e-6 * toti[t]), (t, float(d.max()))
+    d = np.abs(raw[0].astype(np.float64) - tot)
+    assert np.all(d <= 3e-6 * tot)
+
+
+@pytest.mark.gpu
 def test_adapter_shot_noise_follows_the_stream_randomizebox_left(tmp_path):
     """snopt > 0 through the C++ adapter in a fresh process: the adapter reads libc's rand() stream at its first call --
     before the HIP runtime starts, whose threads draw from that stream now and then -- and thins from its own copy, plane
