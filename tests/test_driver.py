@@ -173,6 +173,24 @@ def test_full_run_writes_planes_that_match_the_oracle(tmp_path, partinplanes):
 
 
 @pytest.mark.gpu
+def test_reference_counts_switch_reproduces_the_reference_quirks(tmp_path):
+    """The reference's ntotxyi stays 0 (an inner array shadows the out-parameter, densitymaps.cpp:497): its FITS headers
+    carry NPARTTYPE* = 0 and, with partinplanes, `if (ntotxyi[i] > 0)` (densitymaps.cpp:593) is never true, so no
+    per-type file is ever written.  --reference-counts keeps both quirks; the default writes the real counts."""
+    ini, files, out = make_cone(tmp_path)
+    assert run([ini, "--ngp", "--reference-counts"]).returncode == 0
+    names = sorted(f for f in os.listdir(out) if f.endswith(".fits"))
+    assert len(names) >= 20
+    for f in names:
+        hdr = open(os.path.join(out, f), "rb").read(2880)
+        for t in range(6):
+            assert (b"HIERARCH NPARTTYPE%d = %8d" % (t, 0)) in hdr, (f, t)
+    ini2, _, out2 = make_cone(tmp_path / "pip", partinplanes=1)
+    assert run([ini2, "--ngp", "--reference-counts"]).returncode == 0
+    assert not [f for f in os.listdir(out2) if f.endswith(".fits")]
+
+
+@pytest.mark.gpu
 def test_full_run_with_lateral_replication(tmp_path):
     """--replication (the reference's -DReplicationOnPerpendicularPlane): a 60-degree field is wider than the box from the
     second box replication on, so the planner gives the far planes lateral copies of the box (computeReplications) and the
