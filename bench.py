@@ -75,6 +75,9 @@ def parse():
                          "stay on the rank that built them, as for N = 1 (snapshots and lens planes are independent: each "
                          "rank would write its own planes); the gathering variant is timed in the same run as "
                          "config.reduce_layout.steps_gather")
+    ap.add_argument("--secondary-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the secondary layouts (config.reduce_layout) may take before the line is printed "
+                         "without them")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: wait for each step's rank sum before the next step")
     ap.add_argument("--reduce-algo", default="rooted", choices=["rooted", "rs_gather", "p2p"],
                     help="--shard files: the per-plane rank sum as one library reduce per map (rooted), as reduce-scatter "
@@ -562,39 +565,8 @@ def main():
     if rank == 0 and world == 1 and (a.e2e == "on" or (a.e2e == "auto" and a.cpu != "off")):
         e2e = end_to_end(a)
 
-    # ---- the reference's own multi-rank layout in the same run (VERDICT r2 #2): sub-files of every snapshot split over
-    # the ranks (slicer-v2.cpp:162-175) + the per-plane sum to rank 0 over RCCL (slicer-v2.cpp:214-217), timed with the
-    # library's rooted reduce and with the direct reduce-scatter + gather-to-root (SURVEY S5), on the same boxes
+    out = None
     reduce_layout = None
-    want_reduce_layout = a.reduce_layout == "on" or (a.reduce_layout == "auto" and world > 1)
-    if use_dist and want_reduce_layout and shard != "files":
-        L.close()
-        reduce_layout = {}
-        for ralgo in ("rooted", "p2p"):
-            try:
-                L2 = Layout("files", ralgo)
-                dt2, dep2, in2 = L2.run()
-                reduce_layout[ralgo] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2, "n_in_per_s": in2 / dt2,
-                                        "overlap": L2.overlap}
-                L2.close()
-            except Exception as e:  # the main number must survive a failing secondary layout
-                reduce_layout[ralgo] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if shard == "steps" and not gathered:  # the step layout WITH the maps travelling to rank 0
-            try:
-                L2 = Layout("steps", a.reduce_algo, gather=True)
-                dt2, dep2, in2 = L2.run()
-                reduce_layout["steps_gather"] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2,
-                                                 "n_in_per_s": in2 / dt2, "overlap": L2.overlap}
-                L2.close()
-            except Exception as e:
-                reduce_layout["steps_gather"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        reduce_layout["what"] = ("--shard files: every snapshot's sub-files in contiguous ranges over the ranks "
-                                 "(slicer-v2.cpp:162-175) + per-plane sum to rank 0 in the accumulator type over RCCL "
-                                 "(slicer-v2.cpp:214-217); rooted = one library reduce per map, p2p = direct "
-                                 "reduce-scatter + gather-to-root as grouped sends / receives (slicer_amd/parallel.py); "
-                                 "steps_gather = the step layout of `value` with every finished map also sent to rank 0 "
-                                 "point to point (parallel.StepGather); same boxes, steps and timing protocol as `value`")
-
     if rank == 0:
         out = {
             "metric": "particles/s deposited (TSC, 4096^2 map)" if (a.mas == "tsc" and a.npix == 4096)
@@ -617,7 +589,7 @@ def main():
                 "shard": shard, "algo": a.algo, "accum": a.accum, "algo_mask": algo_mask,
                 "streams": max(1, a.streams) if not use_dist else None,
                 "reduce_algo": a.reduce_algo if reduce_steps else None,
-                "reduce_layout": reduce_layout,
+                "reduce_layout": None,  # (filled in below, after the main number is safe)
                 "collective": (("per-plane sum to rank 0 in the accumulator type over RCCL, " if reduce_steps else
                                 "finished plane maps sent to rank 0 point to point over RCCL, ")
                                + ("overlapped with the following steps" if overlap else "not overlapped"))
@@ -644,6 +616,63 @@ def main():
             "e2e": e2e,
             "cpu_baseline": cpu,
         }
+
+    # ---- the reference's own multi-rank layout in the same run (VERDICT r2 #2): sub-files of every snapshot split over
+    # the ranks (slicer-v2.cpp:162-175) + the per-plane sum to rank 0 over RCCL (slicer-v2.cpp:214-217), timed with the
+    # library's rooted reduce and with the direct reduce-scatter + gather-to-root (SURVEY S5), on the same boxes
+    want_reduce_layout = a.reduce_layout == "on" or (a.reduce_layout == "auto" and world > 1)
+    if use_dist and want_reduce_layout and shard != "files":
+        L.close()
+        reduce_layout = {}
+        # The secondary layouts are collectives that have never met real multi-GPU hardware before the scaling run: if one
+        # of them hangs, the main number -- measured and complete at this point -- must still reach stdout.  Every rank
+        # arms the same timer; when it fires rank 0 prints the line with what finished and all ranks leave.
+        import threading
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                rl = dict(reduce_layout)
+                rl["error"] = f"the secondary layouts did not finish within {a.secondary_timeout} s and were cut off"
+                out["config"]["reduce_layout"] = rl
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(a.secondary_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        for ralgo in ("rooted", "p2p"):
+            try:
+                L2 = Layout("files", ralgo)
+                dt2, dep2, in2 = L2.run()
+                reduce_layout[ralgo] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2, "n_in_per_s": in2 / dt2,
+                                        "overlap": L2.overlap}
+                L2.close()
+            except Exception as e:  # the main number must survive a failing secondary layout
+                reduce_layout[ralgo] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if shard == "steps" and not gathered:  # the step layout WITH the maps travelling to rank 0
+            try:
+                L2 = Layout("steps", a.reduce_algo, gather=True)
+                dt2, dep2, in2 = L2.run()
+                reduce_layout["steps_gather"] = {"ms_per_step": 1e3 * dt2 / a.steps, "value": dep2 / dt2,
+                                                 "n_in_per_s": in2 / dt2, "overlap": L2.overlap}
+                L2.close()
+            except Exception as e:
+                reduce_layout["steps_gather"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        reduce_layout["what"] = ("--shard files: every snapshot's sub-files in contiguous ranges over the ranks "
+                                 "(slicer-v2.cpp:162-175) + per-plane sum to rank 0 in the accumulator type over RCCL "
+                                 "(slicer-v2.cpp:214-217); rooted = one library reduce per map, p2p = direct "
+                                 "reduce-scatter + gather-to-root as grouped sends / receives (slicer_amd/parallel.py); "
+                                 "steps_gather = the step layout of `value` with every finished map also sent to rank 0 "
+                                 "point to point (parallel.StepGather); same boxes, steps and timing protocol as `value`")
+        finished.set()
+        watchdog.cancel()
+
+
+    if rank == 0:
+        out["config"]["reduce_layout"] = reduce_layout
         print(json.dumps(out), flush=True)
     L.close()
     if use_dist:

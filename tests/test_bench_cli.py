@@ -51,3 +51,13 @@ def test_one_run_times_the_step_layout_and_the_per_plane_reduce_layout():
         # one-rank group moves nothing); a sum that stalled the pipeline would show here
         # (this tiny job is 0.2 ms per step: the fixed costs of a collective round show; the headline job: 1.9 vs 2.0 ms)
         assert rl[algo]["value"] > 0.2 * d["value"], (rl[algo], d["value"])
+
+
+def test_a_stuck_secondary_layout_cannot_take_the_main_number_down():
+    """N > 1 runs time the reduce layouts after the main number; those collectives meet real multi-GPU hardware for the
+    first time in the scaling run.  A watchdog prints the line with whatever finished and leaves if they do not finish in
+    time -- here the time allowed is zero."""
+    d = _bench(SMALL + ["--shard", "steps", "--reduce-layout", "on", "--secondary-timeout", "0.001"],
+               env={"SLICER_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29534"})
+    assert d["value"] > 0 and d["config"]["shard"] == "steps"
+    assert "cut off" in d["config"]["reduce_layout"]["error"]
